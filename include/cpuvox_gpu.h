@@ -1,0 +1,193 @@
+/*
+ * cpuvox_gpu.h -- the drop-in boundary: C ABI of libcpuvox_gpu.so.
+ *
+ * The reference (pipliz/cpuvox) has no FFI for this path: the boundary is the
+ * C# static method RenderManager.DrawSegments (Assets/Code/RenderManager.cs:
+ * 258-372) which fills SegmentContext[4]/DrawContext, schedules the four
+ * Burst jobs of Assets/Code/Rendering/DrawSegmentRayJob.cs and blocks on
+ * render.Complete().  Every entry point below cites the reference interface
+ * it replaces; INTEGRATION.md shows the P/Invoke binding a maintainer adds.
+ *
+ * Plain pointers and sizes only; all structs are blittable (C# sequential
+ * layout, Pack = 4).  All functions return CVX_OK (0) or a negative error
+ * code; cvx_last_error() gives the text.  The reference has no error returns
+ * (Burst cannot throw; managed exceptions propagate to UnityManager.cs:184):
+ * the P/Invoke wrapper turns a non-zero code into an exception.
+ *
+ * Threading: one caller thread per context (as the reference: Unity main
+ * thread).  cvx_draw_segments is blocking like DrawSegments unless
+ * CVX_DRAW_ASYNC is passed.
+ */
+#ifndef CPUVOX_GPU_H
+#define CPUVOX_GPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CVX_LOD_LEVELS 6 /* UnityManager.LOD_LEVELS, UnityManager.cs:42 */
+
+enum {
+	CVX_OK = 0,
+	CVX_ERR_INVALID_ARGUMENT = -1,
+	CVX_ERR_HIP = -2,          /* a HIP runtime call failed (no device, OOM, ...) */
+	CVX_ERR_NOT_READY = -3,    /* world / resolution not set */
+	CVX_ERR_CAPACITY = -4,     /* ray count exceeds the raybuffer capacity */
+};
+
+enum {
+	CVX_RAYBUFFER_TOPDOWN = 0,   /* RenderManager.rayBufferTopDown,   RenderManager.cs:16,36 */
+	CVX_RAYBUFFER_LEFTRIGHT = 1, /* RenderManager.rayBufferLeftRight, RenderManager.cs:17,35 */
+};
+
+enum {
+	CVX_DRAW_SYNC = 0,  /* return after the kernels completed (render.Complete(), :363) */
+	CVX_DRAW_ASYNC = 1, /* enqueue only; cvx_synchronize() or a read-back completes it */
+};
+
+/* RenderManager.SegmentData, RenderManager.cs:503-510 (36 bytes). */
+typedef struct cvx_segment_data {
+	float MinScreen[2];
+	float MaxScreen[2];
+	float CamLocalPlaneRayMin[2];
+	float CamLocalPlaneRayMax[2];
+	int32_t RayCount;
+} cvx_segment_data;
+
+/* CameraData, CameraData.cs:11-16 (108 bytes).  WorldToScreenMatrix is
+ * column major (c0,c1,c2,c3), the memory order of Unity.Mathematics.float4x4.
+ * InverseElementIterationDirection is the C# bool (1 byte) + padding. */
+typedef struct cvx_camera_data {
+	float WorldToScreenMatrix[16];
+	float PositionXZ[2];
+	float PositionY;
+	uint8_t InverseElementIterationDirection;
+	uint8_t pad_[3];
+	float FarClip;
+	float LODDistances[CVX_LOD_LEVELS];
+} cvx_camera_data;
+
+/* Work counters of the last draw (optional instrumentation):
+ * algorithmic bytes B = 12*S + 4*E + 4*C + 4*P + 80*R. */
+typedef struct cvx_counters {
+	int64_t S, E, C, P, R;
+	int64_t lodVisits[CVX_LOD_LEVELS];
+} cvx_counters;
+
+typedef struct cvx_context cvx_context;
+
+/* Lifetime of what RenderManager owns (ctor RenderManager.cs:25-41, Destroy :43-51).
+ * device = HIP device ordinal. */
+int cvx_create(int device, cvx_context **out);
+void cvx_destroy(cvx_context *ctx);
+const char *cvx_last_error(const cvx_context *ctx); /* ctx may be NULL: creation errors */
+
+/* Use an externally owned HIP stream (hipStream_t as void*) for all work of
+ * this context; NULL = the context's own stream. */
+int cvx_set_stream(cvx_context *ctx, void *hipStream);
+
+/*
+ * Replaces `new World(dimensions, lod, data)` (World.cs:36-43) + the
+ * `fixed (World* worldPtr = worldLODs)` hand-over (RenderManager.cs:155).
+ * storage = WorldAllocator.GetStartPointer() (World.cs:273): columnCount
+ * 12-byte RLEColumn headers {int32 offset; uint16 runCount, worldMin,
+ * worldMax} followed by the 4-byte RLEElement/ColorARGB32 pool
+ * (World.cs:161-169,245-259,304-313); byteLength = GetByteLength()
+ * (World.cs:278-283), or the exact used length.  columnCount =
+ * World.ColumnCount (World.cs:17) = where the element pool starts.
+ * The data is copied to the device (and re-laid-out); the caller keeps
+ * ownership of storage.  Dimensions must be powers of two (WordBuilder.cs:30).
+ */
+int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byteLength,
+                     int dimX, int dimY, int dimZ, int columnCount);
+
+/* RenderManager.SetResolution, RenderManager.cs:94-109: (re)allocates the
+ * raybuffers: top-down = width H, capacity W+2H rays; left-right = width W,
+ * capacity 2W+H rays (RenderManager.cs:35-36), times bufferCount. */
+int cvx_set_resolution(cvx_context *ctx, int resolutionX, int resolutionY);
+
+/* RenderManager.BUFFER_COUNT (RenderManager.cs:14) is 2; a GPU pipeline that
+ * keeps many frames in flight may ask for more.  Call before cvx_set_resolution. */
+int cvx_set_buffer_count(cvx_context *ctx, int bufferCount);
+
+/*
+ * RenderManager.DrawSegments, RenderManager.cs:258-372: same argument set
+ * (segments[4], camera, screen size, vanishing point); worldLODs are the
+ * uploaded ones; bufferIndex selects the raybuffer pair (RenderManager.
+ * bufferIndex, :19,53-56).  Runs RaySetupJob, DDASetupJob,
+ * TraceToFirstColumnJob and RenderJob (DrawSegmentRayJob.cs:12,49,87,156)
+ * as HIP kernels.
+ */
+int cvx_draw_segments(cvx_context *ctx, const cvx_segment_data segments[4], const cvx_camera_data *camera,
+                      int screenWidth, int screenHeight, const float vanishingPointScreenSpace[2],
+                      int bufferIndex, int flags);
+
+/* Many independent frames in one launch (frame i -> buffer (firstBufferIndex+i) % bufferCount).
+ * segments: frameCount*4 entries; cameras, vanishingPoints (x,y pairs): frameCount entries. */
+int cvx_draw_segments_batch(cvx_context *ctx, int frameCount, const cvx_segment_data *segments,
+                            const cvx_camera_data *cameras, int screenWidth, int screenHeight,
+                            const float *vanishingPoints, int firstBufferIndex, int flags);
+
+/* Multi-GPU sharding: this context renders only the 64-ray
+ * tiles t with t % shardCount == shardIndex.  Default (0, 1) = everything. */
+int cvx_set_shard(cvx_context *ctx, int shardIndex, int shardCount);
+
+int cvx_synchronize(cvx_context *ctx);
+
+/* RenderManager.ClearRayBuffer, RenderManager.cs:58-92 (fills with one ARGB32
+ * value, bytes A,R,G,B in memory order packed little-endian in `argb`). */
+int cvx_clear_raybuffer(cvx_context *ctx, int bufferIndex, int which, uint32_t argb);
+
+/*
+ * Read back rows of a raybuffer in the reference's logical layout
+ * (RayBuffer.Native.GetRayColumn, RayBuffer.cs:121-128): ray r of the buffer
+ * = `width` contiguous ARGB32 pixels, rows [firstRay, firstRay+rayCount).
+ * dst is host memory of rayCount*width*4 bytes.  Only rows rendered by the
+ * last draw into that buffer are defined (others keep the cleared value).
+ */
+int cvx_read_raybuffer(cvx_context *ctx, int bufferIndex, int which, int firstRay, int rayCount, void *dst);
+
+/*
+ * RenderManager.BlitSegments (RenderManager.cs:199-256) + RayBufferBlit.shader
+ * frag (Assets/Shaders/RayBufferBlit.shader:48-64): Phase 2, raybuffer ->
+ * W x H ARGB32 screen image (row 0 = bottom row, Unity screen space).  Uses
+ * the segments / vanishing point of the last draw into bufferIndex.
+ * dstHost may be NULL (image stays on the device, see cvx_screen_device_ptr).
+ */
+int cvx_blit_segments(cvx_context *ctx, int bufferIndex, void *dstHost);
+
+/* Device pointers for zero-copy consumers (RCCL gather, torch tensors). */
+int cvx_raybuffer_device_ptr(cvx_context *ctx, int bufferIndex, int which, void **ptr, int64_t *bytes);
+int cvx_screen_device_ptr(cvx_context *ctx, void **ptr, int64_t *bytes);
+
+/* Timing of the last draw call, measured with HIP events on the context's
+ * stream (milliseconds; kernels only, no host setup). */
+int cvx_last_draw_ms(cvx_context *ctx, float *ms);
+
+/* Enable in-kernel work counters (slower); read them after a SYNC draw. */
+int cvx_enable_counters(cvx_context *ctx, int enable);
+int cvx_get_counters(cvx_context *ctx, cvx_counters *out);
+
+/* Device layout description of the tile-major raybuffer (for gathers/tests). */
+typedef struct cvx_raybuffer_layout {
+	int32_t width;         /* pixels per ray: H (top-down) or W (left-right) */
+	int32_t rayCapacity;   /* W+2H or 2W+H */
+	int32_t tileRays;      /* 64 */
+	int32_t tileCapacity;  /* tiles allocated */
+	int64_t tileBytes;     /* width * 64 * 4 */
+} cvx_raybuffer_layout;
+int cvx_get_raybuffer_layout(cvx_context *ctx, int which, cvx_raybuffer_layout *out);
+
+/* Arithmetic self-test hook used by tests: evaluates op on n float pairs on
+ * the device.  op: 0 a/b, 1 sqrt(a), 2 1/sqrt(a), 3 a*b+c style lerp a+b*(b-a),
+ * 4 floor, 5 ceil, 6 round-half-even, 7 (int)a with the x86 rule. */
+int cvx_selftest_math(cvx_context *ctx, int op, int n, const float *a, const float *b, float *out);
+
+const char *cvx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
