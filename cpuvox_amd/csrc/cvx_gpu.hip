@@ -1,0 +1,818 @@
+// cvx_gpu.hip -- libcpuvox_gpu.so: the C-ABI drop-in for
+// RenderManager.DrawSegments (Assets/Code/RenderManager.cs:258-372) on MI355X.
+// See include/cpuvox_gpu.h for the contract of every entry point.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "cpuvox_gpu.h"
+#include "cvx_device.h"
+#include "cvx_kernels.h"
+
+namespace {
+
+std::string g_createError; // cvx_last_error(NULL)
+
+struct RefHeader { // World.RLEColumn, World.cs:161-169
+	int32_t storageOffset;
+	uint16_t runCount;
+	uint16_t worldMin;
+	uint16_t worldMax;
+};
+static_assert(sizeof(RefHeader) == 12, "reference header is 12 bytes");
+
+struct LastDraw { // what read-back / blit need to know about a buffer pair
+	bool valid = false;
+	cvx_segment_data segments[4];
+	float vp[2];
+	int tileBase[4];
+	int width = 0, height = 0;
+};
+
+} // namespace
+
+struct cvx_context {
+	int device = 0;
+	hipStream_t ownStream = nullptr;
+	hipStream_t stream = nullptr;
+	// one HIP event pair per draw since the last cvx_draw_time_stats(reset): kernel time on ctx->stream
+	std::vector<hipEvent_t> evPairs; // 2 * pairs
+	size_t evUsed = 0;               // pairs in use
+	double accumulatedMs = 0.0;      // folded-in pairs
+	int accumulatedDraws = 0;
+	float lastMs = 0.f;
+	std::string error;
+
+	// world
+	void *levelHeaders[CVX_LOD_LEVELS] = {};
+	void *levelElements[CVX_LOD_LEVELS] = {};
+	bool levelSet[CVX_LOD_LEVELS] = {};
+	DevWorld hostWorld{};
+	DevWorld *devWorld = nullptr;
+	bool worldDirty = true;
+
+	// raybuffers
+	int resX = 0, resY = 0;
+	int bufferCount = 2; // RenderManager.BUFFER_COUNT, RenderManager.cs:14
+	int tilesTD = 0, tilesLR = 0;
+	size_t poolBytesTD = 0, poolBytesLR = 0;
+	std::vector<uint32_t *> poolTD, poolLR; // per buffer: offsets into one allocation each
+	uint32_t *poolBaseTD = nullptr, *poolBaseLR = nullptr;
+	bool poolsExternal = false;
+	std::vector<LastDraw> last;
+	uint32_t *screen = nullptr;
+	uint32_t *staging = nullptr;
+	size_t stagingBytes = 0;
+
+	// per-draw scratch (grown on demand, reused)
+	DevFrame *devFrames = nullptr;
+	size_t devFramesCap = 0;
+	DevTile *devTiles = nullptr;
+	size_t devTilesCap = 0;
+	std::vector<DevFrame> hostFrames;
+	std::vector<DevTile> hostTiles;
+
+	int shardIndex = 0, shardCount = 1;
+	bool countersEnabled = false;
+	DevCounters *devCounters = nullptr;
+};
+
+namespace {
+
+int Fail(cvx_context *ctx, int code, const char *fmt, ...)
+{
+	char buf[512];
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(buf, sizeof buf, fmt, ap);
+	va_end(ap);
+	if (ctx) {
+		ctx->error = buf;
+	} else {
+		g_createError = buf;
+	}
+	return code;
+}
+
+#define CVX_HIP(ctx, call)                                                                                              \
+	do {                                                                                                                \
+		hipError_t e_ = (call);                                                                                         \
+		if (e_ != hipSuccess) {                                                                                         \
+			return Fail(ctx, CVX_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__);   \
+		}                                                                                                               \
+	} while (0)
+
+bool IsPow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+void FreeRaybuffers(cvx_context *ctx)
+{
+	if (!ctx->poolsExternal) {
+		if (ctx->poolBaseTD) { (void)hipFree(ctx->poolBaseTD); }
+		if (ctx->poolBaseLR) { (void)hipFree(ctx->poolBaseLR); }
+	}
+	ctx->poolBaseTD = ctx->poolBaseLR = nullptr;
+	ctx->poolsExternal = false;
+	ctx->poolTD.clear();
+	ctx->poolLR.clear();
+	ctx->last.clear();
+	if (ctx->screen) { (void)hipFree(ctx->screen); ctx->screen = nullptr; }
+	ctx->resX = ctx->resY = 0;
+}
+
+// Mathf.RoundToInt (half to even) then clamp, RenderManager.cs:302-311
+int RoundClamp(float v, int lo, int hi)
+{
+	float r = std::nearbyint(v);
+	int i = (r != r || r >= 2147483648.0f || r < -2147483648.0f) ? (int)0x80000000 : (int)r;
+	return i < lo ? lo : (i > hi ? hi : i);
+}
+
+bool Finite(const float *v, int n)
+{
+	for (int i = 0; i < n; i++) {
+		if (!std::isfinite(v[i])) { return false; }
+	}
+	return true;
+}
+
+int EnsureScratch(cvx_context *ctx, size_t frames, size_t tiles)
+{
+	if (frames > ctx->devFramesCap) {
+		if (ctx->devFrames) { (void)hipFree(ctx->devFrames); ctx->devFrames = nullptr; }
+		size_t cap = frames + frames / 2 + 4;
+		CVX_HIP(ctx, hipMalloc((void **)&ctx->devFrames, cap * sizeof(DevFrame)));
+		ctx->devFramesCap = cap;
+	}
+	if (tiles > ctx->devTilesCap) {
+		if (ctx->devTiles) { (void)hipFree(ctx->devTiles); ctx->devTiles = nullptr; }
+		size_t cap = tiles + tiles / 2 + 64;
+		CVX_HIP(ctx, hipMalloc((void **)&ctx->devTiles, cap * sizeof(DevTile)));
+		ctx->devTilesCap = cap;
+	}
+	return CVX_OK;
+}
+
+// Fills SegmentContext[4] the way DrawSegments does (RenderManager.cs:281-318)
+// and appends this frame's tiles.
+int BuildFrame(cvx_context *ctx, const cvx_segment_data segments[4], const cvx_camera_data *camera, int W, int H, const float vp[2],
+               int bufferIndex, int frameIndex, DevFrame &F, std::vector<DevTile> &tiles, LastDraw &last)
+{
+	if (!Finite(camera->WorldToScreenMatrix, 16) || !Finite(camera->PositionXZ, 2) || !Finite(&camera->PositionY, 1) ||
+	    !Finite(&camera->FarClip, 1) || !Finite(camera->LODDistances, CVX_LOD_LEVELS) || !Finite(vp, 2)) {
+		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "camera data / vanishing point contains a non-finite value");
+	}
+	std::memcpy(F.M, camera->WorldToScreenMatrix, sizeof F.M);
+	F.posX = camera->PositionXZ[0];
+	F.posZ = camera->PositionXZ[1];
+	F.posY = camera->PositionY;
+	F.farClip = camera->FarClip;
+	for (int i = 0; i < CVX_LOD_LEVELS; i++) { F.lod[i] = camera->LODDistances[i]; }
+	F.inverse = camera->InverseElementIterationDirection ? 1 : 0;
+	F.pad_ = 0;
+	F.poolTD = ctx->poolTD[(size_t)bufferIndex];
+	F.poolLR = ctx->poolLR[(size_t)bufferIndex];
+
+	last.valid = true;
+	last.width = W;
+	last.height = H;
+	last.vp[0] = vp[0];
+	last.vp[1] = vp[1];
+	std::memcpy(last.segments, segments, sizeof last.segments);
+
+	int tileIdInFrame = 0;
+	for (int s = 0; s < 4; s++) {
+		DevSegment &S = F.seg[s];
+		std::memset(&S, 0, sizeof S);
+		const cvx_segment_data &seg = segments[s];
+		int rayCount = seg.RayCount > 0 ? seg.RayCount : 0;
+		S.rayCount = rayCount;
+		S.axisMappedToY = s > 1 ? 0 : 1;
+		S.colLen = s < 2 ? H : W;
+		// tiles of segment 1 / 3 follow those of segment 0 / 2 in the pool
+		S.tileBase = (s == 1 || s == 3) ? (F.seg[s - 1].tileBase + (F.seg[s - 1].rayCount + CVX_WAVE - 1) / CVX_WAVE) : 0;
+		last.tileBase[s] = S.tileBase;
+		if (rayCount <= 0) {
+			continue;
+		}
+		if (!Finite(seg.CamLocalPlaneRayMin, 2) || !Finite(seg.CamLocalPlaneRayMax, 2)) {
+			return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "segment %d has non-finite plane rays", s);
+		}
+		S.rayMinX = seg.CamLocalPlaneRayMin[0];
+		S.rayMinZ = seg.CamLocalPlaneRayMin[1];
+		S.rayMaxX = seg.CamLocalPlaneRayMax[0];
+		S.rayMaxZ = seg.CamLocalPlaneRayMax[1];
+		if (s == 0) { // top
+			S.omin = RoundClamp(vp[1], 0, H - 1);
+			S.omax = H - 1;
+		} else if (s == 1) { // bottom
+			S.omin = 0;
+			S.omax = RoundClamp(vp[1], 0, H - 1);
+		} else if (s == 3) { // left
+			S.omin = 0;
+			S.omax = RoundClamp(vp[0], 0, W - 1);
+		} else { // right
+			S.omin = RoundClamp(vp[0], 0, W - 1);
+			S.omax = W - 1;
+		}
+		int segTiles = (rayCount + CVX_WAVE - 1) / CVX_WAVE;
+		int capacity = s < 2 ? ctx->tilesTD : ctx->tilesLR;
+		if (S.tileBase + segTiles > capacity) {
+			return Fail(ctx, CVX_ERR_CAPACITY, "segment %d: %d rays exceed the raybuffer capacity (RenderManager.cs:35-36)", s, rayCount);
+		}
+		for (int t = 0; t < segTiles; t++, tileIdInFrame++) {
+			if (tileIdInFrame % ctx->shardCount != ctx->shardIndex) {
+				continue;
+			}
+			tiles.push_back(DevTile{ frameIndex, s, t, 0 });
+		}
+	}
+	// reference capacity check: TopDown holds W+2H rays, LeftRight 2W+H
+	if ((int64_t)F.seg[0].rayCount + F.seg[1].rayCount > (int64_t)W + 2 * H || (int64_t)F.seg[2].rayCount + F.seg[3].rayCount > (int64_t)2 * W + H) {
+		return Fail(ctx, CVX_ERR_CAPACITY, "ray counts exceed the raybuffer capacity (RenderManager.cs:35-36)");
+	}
+	return CVX_OK;
+}
+
+// Folds all pending event pairs into accumulatedMs (waits for them).
+int FoldEvents(cvx_context *ctx)
+{
+	for (size_t i = 0; i < ctx->evUsed; i++) {
+		float ms = 0.f;
+		CVX_HIP(ctx, hipEventSynchronize(ctx->evPairs[2 * i + 1]));
+		CVX_HIP(ctx, hipEventElapsedTime(&ms, ctx->evPairs[2 * i], ctx->evPairs[2 * i + 1]));
+		ctx->accumulatedMs += ms;
+		ctx->accumulatedDraws++;
+		ctx->lastMs = ms;
+	}
+	ctx->evUsed = 0;
+	return CVX_OK;
+}
+
+int NextEventPair(cvx_context *ctx, hipEvent_t &start, hipEvent_t &stop)
+{
+	if (ctx->evUsed >= 1024) {
+		int rc = FoldEvents(ctx);
+		if (rc != CVX_OK) { return rc; }
+	}
+	if (ctx->evPairs.size() < 2 * (ctx->evUsed + 1)) {
+		hipEvent_t a = nullptr, b = nullptr;
+		CVX_HIP(ctx, hipEventCreate(&a));
+		CVX_HIP(ctx, hipEventCreate(&b));
+		ctx->evPairs.push_back(a);
+		ctx->evPairs.push_back(b);
+	}
+	start = ctx->evPairs[2 * ctx->evUsed];
+	stop = ctx->evPairs[2 * ctx->evUsed + 1];
+	ctx->evUsed++;
+	return CVX_OK;
+}
+
+int SyncWorld(cvx_context *ctx)
+{
+	if (!ctx->levelSet[0]) {
+		return Fail(ctx, CVX_ERR_NOT_READY, "world LOD 0 has not been uploaded");
+	}
+	if (ctx->worldDirty) {
+		// Missing higher LODs alias the last uploaded one only if never reached; require all 6 like the reference's World[6].
+		for (int i = 0; i < CVX_LOD_LEVELS; i++) {
+			if (!ctx->levelSet[i]) {
+				return Fail(ctx, CVX_ERR_NOT_READY, "world LOD %d has not been uploaded (UnityManager.LOD_LEVELS = 6)", i);
+			}
+		}
+		if (!ctx->devWorld) {
+			CVX_HIP(ctx, hipMalloc((void **)&ctx->devWorld, sizeof(DevWorld)));
+		}
+		CVX_HIP(ctx, hipMemcpyAsync(ctx->devWorld, &ctx->hostWorld, sizeof(DevWorld), hipMemcpyHostToDevice, ctx->stream));
+		CVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		ctx->worldDirty = false;
+	}
+	return CVX_OK;
+}
+
+int Launch(cvx_context *ctx, int frameCount, int W, int H, int flags)
+{
+	size_t nTiles = ctx->hostTiles.size();
+	int rc = EnsureScratch(ctx, (size_t)frameCount, nTiles);
+	if (rc != CVX_OK) { return rc; }
+	CVX_HIP(ctx, hipMemcpyAsync(ctx->devFrames, ctx->hostFrames.data(), (size_t)frameCount * sizeof(DevFrame), hipMemcpyHostToDevice, ctx->stream));
+	if (nTiles) {
+		CVX_HIP(ctx, hipMemcpyAsync(ctx->devTiles, ctx->hostTiles.data(), nTiles * sizeof(DevTile), hipMemcpyHostToDevice, ctx->stream));
+	}
+	if (ctx->countersEnabled) {
+		CVX_HIP(ctx, hipMemsetAsync(ctx->devCounters, 0, sizeof(DevCounters), ctx->stream));
+	}
+	hipEvent_t evStart = nullptr, evStop = nullptr;
+	rc = NextEventPair(ctx, evStart, evStop);
+	if (rc != CVX_OK) { return rc; }
+	CVX_HIP(ctx, hipEventRecord(evStart, ctx->stream));
+	if (nTiles) {
+		// All frames of one call share the iteration direction only if their
+		// cameras agree; split the launch per direction (RenderJob.Execute :174-178).
+		size_t begin = 0;
+		const int maxLen = W > H ? W : H;
+		const size_t ldsBytes = (size_t)((maxLen + 31) / 32) * CVX_WAVE * sizeof(uint32_t);
+		while (begin < nTiles) {
+			const int inverse = ctx->hostFrames[(size_t)ctx->hostTiles[begin].frame].inverse;
+			size_t end = begin;
+			while (end < nTiles && ctx->hostFrames[(size_t)ctx->hostTiles[end].frame].inverse == inverse) { end++; }
+			dim3 grid((unsigned)(end - begin)), block(CVX_WAVE);
+			const DevTile *tiles = ctx->devTiles + begin;
+			if (ctx->countersEnabled) {
+				if (inverse) {
+					hipLaunchKernelGGL((cvxk::render_kernel<-1, true>), grid, block, ldsBytes, ctx->stream, ctx->devFrames, tiles, ctx->devWorld, ctx->devCounters);
+				} else {
+					hipLaunchKernelGGL((cvxk::render_kernel<1, true>), grid, block, ldsBytes, ctx->stream, ctx->devFrames, tiles, ctx->devWorld, ctx->devCounters);
+				}
+			} else {
+				if (inverse) {
+					hipLaunchKernelGGL((cvxk::render_kernel<-1, false>), grid, block, ldsBytes, ctx->stream, ctx->devFrames, tiles, ctx->devWorld, ctx->devCounters);
+				} else {
+					hipLaunchKernelGGL((cvxk::render_kernel<1, false>), grid, block, ldsBytes, ctx->stream, ctx->devFrames, tiles, ctx->devWorld, ctx->devCounters);
+				}
+			}
+			CVX_HIP(ctx, hipGetLastError());
+			begin = end;
+		}
+	}
+	CVX_HIP(ctx, hipEventRecord(evStop, ctx->stream));
+	if (!(flags & CVX_DRAW_ASYNC)) {
+		CVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	}
+	return CVX_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *cvx_version(void) { return "cpuvox_gpu 0.1 (gfx950)"; }
+
+const char *cvx_last_error(const cvx_context *ctx) { return ctx ? ctx->error.c_str() : g_createError.c_str(); }
+
+int cvx_create(int device, cvx_context **out)
+{
+	if (!out) { return Fail(nullptr, CVX_ERR_INVALID_ARGUMENT, "out is NULL"); }
+	*out = nullptr;
+	int count = 0;
+	hipError_t e = hipGetDeviceCount(&count);
+	if (e != hipSuccess || count <= 0) {
+		return Fail(nullptr, CVX_ERR_HIP, "no HIP device available: %s", e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+	}
+	if (device < 0 || device >= count) { return Fail(nullptr, CVX_ERR_INVALID_ARGUMENT, "device %d out of range (%d devices)", device, count); }
+	cvx_context *ctx = new (std::nothrow) cvx_context();
+	if (!ctx) { return Fail(nullptr, CVX_ERR_HIP, "out of host memory"); }
+	ctx->device = device;
+	auto bail = [&](hipError_t err, const char *what) {
+		Fail(nullptr, CVX_ERR_HIP, "%s failed: %s", what, hipGetErrorString(err));
+		cvx_destroy(ctx);
+		return CVX_ERR_HIP;
+	};
+	if ((e = hipSetDevice(device)) != hipSuccess) { return bail(e, "hipSetDevice"); }
+	if ((e = hipStreamCreateWithFlags(&ctx->ownStream, hipStreamNonBlocking)) != hipSuccess) { return bail(e, "hipStreamCreate"); }
+	ctx->stream = ctx->ownStream;
+	if ((e = hipMalloc((void **)&ctx->devCounters, sizeof(DevCounters))) != hipSuccess) { return bail(e, "hipMalloc"); }
+	*out = ctx;
+	return CVX_OK;
+}
+
+void cvx_destroy(cvx_context *ctx)
+{
+	if (!ctx) { return; }
+	(void)hipSetDevice(ctx->device);
+	if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
+	FreeRaybuffers(ctx);
+	for (int i = 0; i < CVX_LOD_LEVELS; i++) {
+		if (ctx->levelHeaders[i]) { (void)hipFree(ctx->levelHeaders[i]); }
+		if (ctx->levelElements[i]) { (void)hipFree(ctx->levelElements[i]); }
+	}
+	if (ctx->devWorld) { (void)hipFree(ctx->devWorld); }
+	if (ctx->devFrames) { (void)hipFree(ctx->devFrames); }
+	if (ctx->devTiles) { (void)hipFree(ctx->devTiles); }
+	if (ctx->devCounters) { (void)hipFree(ctx->devCounters); }
+	if (ctx->staging) { (void)hipFree(ctx->staging); }
+	for (hipEvent_t e : ctx->evPairs) { (void)hipEventDestroy(e); }
+	if (ctx->ownStream) { (void)hipStreamDestroy(ctx->ownStream); }
+	delete ctx;
+}
+
+int cvx_set_stream(cvx_context *ctx, void *hipStream)
+{
+	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
+	CVX_HIP(ctx, hipSetDevice(ctx->device));
+	CVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	ctx->stream = hipStream ? (hipStream_t)hipStream : ctx->ownStream;
+	return CVX_OK;
+}
+
+int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byteLength, int dimX, int dimY, int dimZ, int columnCount)
+{
+	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
+	if (!storage || lod < 0 || lod >= CVX_LOD_LEVELS) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "bad storage / lod"); }
+	if (!IsPow2(dimX) || !IsPow2(dimY) || !IsPow2(dimZ) || dimY > 65536) {
+		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "world dimensions must be powers of two (WordBuilder.cs:30), Y <= 65536");
+	}
+	if (lod > 0 && (ctx->hostWorld.dimX != dimX || ctx->hostWorld.dimY != dimY || ctx->hostWorld.dimZ != dimZ) && ctx->levelSet[0]) {
+		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "all LODs share the LOD-0 dimensions (World.cs:47)");
+	}
+	const int64_t usedX = dimX >> lod, usedZ = dimZ >> lod;
+	const int64_t usedColumns = usedX * usedZ;
+	if (columnCount < usedColumns || (int64_t)columnCount * 12 > byteLength) {
+		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "columnCount %d inconsistent with dims/lod/byteLength", columnCount);
+	}
+	const int64_t elementCount = (byteLength - (int64_t)columnCount * 12) / 4;
+	const RefHeader *src = static_cast<const RefHeader *>(storage);
+	const uint32_t *elements = reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(storage) + (size_t)columnCount * 12);
+
+	// Widen headers to 16 bytes and validate every column so that the kernel's
+	// element walk is guaranteed to terminate inside the pool.
+	std::vector<uint4> headers((size_t)(usedColumns > 0 ? usedColumns : 1));
+	const int maxY = dimY >> lod;
+	for (int64_t i = 0; i < usedColumns; i++) {
+		const RefHeader &h = src[i];
+		uint4 d = { 0u, 0u, 0u, 0u };
+		if (h.runCount > 0) {
+			const int64_t off = h.storageOffset;
+			if (off < 0 || off + h.runCount + 2 > elementCount) {
+				return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "column %lld: element range outside the pool", (long long)i);
+			}
+			if (elements[off] != 0u || elements[off + h.runCount + 1] != 0u) {
+				return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "column %lld: missing element guards (World.cs:205-209)", (long long)i);
+			}
+			int64_t solid = 0, total = 0;
+			for (int r = 0; r < h.runCount; r++) {
+				const uint32_t raw = elements[off + 1 + r];
+				const int colorsIndex = (int)(int16_t)(raw & 0xFFFFu);
+				const int length = (int)(int16_t)(raw >> 16);
+				if (length <= 0) {
+					return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "column %lld: run %d has length %d", (long long)i, r, length);
+				}
+				total += length;
+				if (colorsIndex >= 0) {
+					if (colorsIndex + length > solid) { solid = colorsIndex + length; }
+				}
+			}
+			if (total > maxY || off + h.runCount + 2 + solid > elementCount) {
+				return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "column %lld: runs exceed the world height or colours exceed the pool", (long long)i);
+			}
+			d.x = (uint32_t)h.storageOffset;
+			d.y = (uint32_t)h.runCount | ((uint32_t)h.worldMin << 16);
+			d.z = (uint32_t)h.worldMax;
+		}
+		headers[(size_t)i] = d;
+	}
+
+	CVX_HIP(ctx, hipSetDevice(ctx->device));
+	CVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (ctx->levelHeaders[lod]) { (void)hipFree(ctx->levelHeaders[lod]); ctx->levelHeaders[lod] = nullptr; }
+	if (ctx->levelElements[lod]) { (void)hipFree(ctx->levelElements[lod]); ctx->levelElements[lod] = nullptr; }
+	ctx->levelSet[lod] = false;
+	CVX_HIP(ctx, hipMalloc(&ctx->levelHeaders[lod], headers.size() * sizeof(uint4)));
+	CVX_HIP(ctx, hipMalloc(&ctx->levelElements[lod], (size_t)(elementCount > 0 ? elementCount : 1) * 4));
+	CVX_HIP(ctx, hipMemcpy(ctx->levelHeaders[lod], headers.data(), headers.size() * sizeof(uint4), hipMemcpyHostToDevice));
+	if (elementCount > 0) {
+		CVX_HIP(ctx, hipMemcpy(ctx->levelElements[lod], elements, (size_t)elementCount * 4, hipMemcpyHostToDevice));
+	}
+	DevWorldLevel &L = ctx->hostWorld.level[lod];
+	L.headers = static_cast<const uint4 *>(ctx->levelHeaders[lod]);
+	L.elements = static_cast<const uint32_t *>(ctx->levelElements[lod]);
+	L.shift = lod;
+	L.mulX = dimZ >> lod;
+	if (lod == 0) {
+		ctx->hostWorld.dimX = dimX;
+		ctx->hostWorld.dimY = dimY;
+		ctx->hostWorld.dimZ = dimZ;
+		ctx->hostWorld.maskX = dimX - 1;
+		ctx->hostWorld.maskZ = dimZ - 1;
+	}
+	ctx->levelSet[lod] = true;
+	ctx->worldDirty = true;
+	return CVX_OK;
+}
+
+int cvx_set_buffer_count(cvx_context *ctx, int bufferCount)
+{
+	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
+	if (bufferCount < 1 || bufferCount > 256) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "bufferCount must be in [1, 256]"); }
+	if (bufferCount != ctx->bufferCount) {
+		CVX_HIP(ctx, hipSetDevice(ctx->device));
+		CVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		int rx = ctx->resX, ry = ctx->resY;
+		FreeRaybuffers(ctx);
+		ctx->bufferCount = bufferCount;
+		if (rx > 0) { return cvx_set_resolution(ctx, rx, ry); }
+	}
+	return CVX_OK;
+}
+
+int cvx_set_resolution(cvx_context *ctx, int resolutionX, int resolutionY)
+{
+	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
+	if (resolutionX <= 0 || resolutionY <= 0 || resolutionX > 16384 || resolutionY > 16384) {
+		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "resolution out of range");
+	}
+	if (resolutionX == ctx->resX && resolutionY == ctx->resY && !ctx->poolTD.empty()) {
+		return CVX_OK; // RenderManager.SetResolution returns false when nothing changes (:96,108)
+	}
+	CVX_HIP(ctx, hipSetDevice(ctx->device));
+	CVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	FreeRaybuffers(ctx);
+	const int W = resolutionX, H = resolutionY;
+	// capacities of RenderManager.cs:35-36 in whole tiles, +2 tiles of slack for
+	// the per-segment round-up to 64 rays
+	ctx->tilesTD = (W + 2 * H + CVX_WAVE - 1) / CVX_WAVE + 2;
+	ctx->tilesLR = (2 * W + H + CVX_WAVE - 1) / CVX_WAVE + 2;
+	ctx->poolBytesTD = (size_t)ctx->tilesTD * (size_t)H * CVX_WAVE * 4;
+	ctx->poolBytesLR = (size_t)ctx->tilesLR * (size_t)W * CVX_WAVE * 4;
+	ctx->poolTD.assign((size_t)ctx->bufferCount, nullptr);
+	ctx->poolLR.assign((size_t)ctx->bufferCount, nullptr);
+	ctx->last.assign((size_t)ctx->bufferCount, LastDraw());
+	// all buffers of one kind live back to back in ONE allocation (buffer b at b * poolBytes), so a
+	// consumer can view them as one [bufferCount * tiles, width * 64] array (RCCL exchange of tiles)
+	CVX_HIP(ctx, hipMalloc((void **)&ctx->poolBaseTD, ctx->poolBytesTD * (size_t)ctx->bufferCount));
+	CVX_HIP(ctx, hipMalloc((void **)&ctx->poolBaseLR, ctx->poolBytesLR * (size_t)ctx->bufferCount));
+	CVX_HIP(ctx, hipMemsetAsync(ctx->poolBaseTD, 0, ctx->poolBytesTD * (size_t)ctx->bufferCount, ctx->stream));
+	CVX_HIP(ctx, hipMemsetAsync(ctx->poolBaseLR, 0, ctx->poolBytesLR * (size_t)ctx->bufferCount, ctx->stream));
+	for (int i = 0; i < ctx->bufferCount; i++) {
+		ctx->poolTD[(size_t)i] = ctx->poolBaseTD + (size_t)i * (ctx->poolBytesTD / 4);
+		ctx->poolLR[(size_t)i] = ctx->poolBaseLR + (size_t)i * (ctx->poolBytesLR / 4);
+	}
+	CVX_HIP(ctx, hipMalloc((void **)&ctx->screen, (size_t)W * (size_t)H * 4));
+	CVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	ctx->resX = W;
+	ctx->resY = H;
+	return CVX_OK;
+}
+
+int cvx_bind_raybuffers(cvx_context *ctx, void *topDown, int64_t topDownBytes, void *leftRight, int64_t leftRightBytes)
+{
+	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
+	if (ctx->poolTD.empty()) { return Fail(ctx, CVX_ERR_NOT_READY, "call cvx_set_resolution first"); }
+	if (!topDown || !leftRight || topDownBytes < (int64_t)(ctx->poolBytesTD * (size_t)ctx->bufferCount) ||
+	    leftRightBytes < (int64_t)(ctx->poolBytesLR * (size_t)ctx->bufferCount) || ((uintptr_t)topDown & 255u) || ((uintptr_t)leftRight & 255u)) {
+		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "external raybuffers too small or not 256-byte aligned");
+	}
+	CVX_HIP(ctx, hipSetDevice(ctx->device));
+	CVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (!ctx->poolsExternal) {
+		if (ctx->poolBaseTD) { (void)hipFree(ctx->poolBaseTD); }
+		if (ctx->poolBaseLR) { (void)hipFree(ctx->poolBaseLR); }
+	}
+	ctx->poolsExternal = true;
+	ctx->poolBaseTD = static_cast<uint32_t *>(topDown);
+	ctx->poolBaseLR = static_cast<uint32_t *>(leftRight);
+	for (int i = 0; i < ctx->bufferCount; i++) {
+		ctx->poolTD[(size_t)i] = ctx->poolBaseTD + (size_t)i * (ctx->poolBytesTD / 4);
+		ctx->poolLR[(size_t)i] = ctx->poolBaseLR + (size_t)i * (ctx->poolBytesLR / 4);
+		ctx->last[(size_t)i] = LastDraw();
+	}
+	return CVX_OK;
+}
+
+int cvx_set_shard(cvx_context *ctx, int shardIndex, int shardCount)
+{
+	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
+	if (shardCount < 1 || shardIndex < 0 || shardIndex >= shardCount) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "bad shard %d/%d", shardIndex, shardCount); }
+	ctx->shardIndex = shardIndex;
+	ctx->shardCount = shardCount;
+	return CVX_OK;
+}
+
+int cvx_draw_segments_batch(cvx_context *ctx, int frameCount, const cvx_segment_data *segments, const cvx_camera_data *cameras,
+                            int screenWidth, int screenHeight, const float *vanishingPoints, int firstBufferIndex, int flags)
+{
+	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
+	if (frameCount <= 0 || !segments || !cameras || !vanishingPoints) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "bad frame arguments"); }
+	if (ctx->poolTD.empty() || screenWidth != ctx->resX || screenHeight != ctx->resY) {
+		return Fail(ctx, CVX_ERR_NOT_READY, "cvx_set_resolution(%d, %d) has not been called", screenWidth, screenHeight);
+	}
+	if (firstBufferIndex < 0 || firstBufferIndex >= ctx->bufferCount || frameCount > ctx->bufferCount) {
+		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "buffer index %d / %d frames do not fit bufferCount %d", firstBufferIndex, frameCount, ctx->bufferCount);
+	}
+	CVX_HIP(ctx, hipSetDevice(ctx->device));
+	int rc = SyncWorld(ctx);
+	if (rc != CVX_OK) { return rc; }
+	ctx->hostFrames.assign((size_t)frameCount, DevFrame());
+	ctx->hostTiles.clear();
+	for (int f = 0; f < frameCount; f++) {
+		int b = (firstBufferIndex + f) % ctx->bufferCount;
+		rc = BuildFrame(ctx, segments + (size_t)f * 4, cameras + f, screenWidth, screenHeight, vanishingPoints + (size_t)f * 2, b, f,
+		                ctx->hostFrames[(size_t)f], ctx->hostTiles, ctx->last[(size_t)b]);
+		if (rc != CVX_OK) { return rc; }
+	}
+	// group tiles by iteration direction so that each launch is one template instance
+	if (frameCount > 1) {
+		std::vector<DevTile> sorted;
+		sorted.reserve(ctx->hostTiles.size());
+		for (int pass = 0; pass < 2; pass++) {
+			for (const DevTile &t : ctx->hostTiles) {
+				if (ctx->hostFrames[(size_t)t.frame].inverse == pass) { sorted.push_back(t); }
+			}
+		}
+		ctx->hostTiles.swap(sorted);
+	}
+	return Launch(ctx, frameCount, screenWidth, screenHeight, flags);
+}
+
+int cvx_draw_segments(cvx_context *ctx, const cvx_segment_data segments[4], const cvx_camera_data *camera, int screenWidth, int screenHeight,
+                      const float vanishingPointScreenSpace[2], int bufferIndex, int flags)
+{
+	return cvx_draw_segments_batch(ctx, 1, segments, camera, screenWidth, screenHeight, vanishingPointScreenSpace, bufferIndex, flags);
+}
+
+int cvx_synchronize(cvx_context *ctx)
+{
+	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
+	CVX_HIP(ctx, hipSetDevice(ctx->device));
+	CVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return CVX_OK;
+}
+
+int cvx_clear_raybuffer(cvx_context *ctx, int bufferIndex, int which, uint32_t argb)
+{
+	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
+	if (ctx->poolTD.empty() || bufferIndex < 0 || bufferIndex >= ctx->bufferCount || (which != 0 && which != 1)) {
+		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "bad buffer selection");
+	}
+	CVX_HIP(ctx, hipSetDevice(ctx->device));
+	uint32_t *p = which == 0 ? ctx->poolTD[(size_t)bufferIndex] : ctx->poolLR[(size_t)bufferIndex];
+	size_t bytes = which == 0 ? ctx->poolBytesTD : ctx->poolBytesLR;
+	CVX_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)p, (int)argb, bytes / 4, ctx->stream));
+	return CVX_OK;
+}
+
+int cvx_read_raybuffer(cvx_context *ctx, int bufferIndex, int which, int firstRay, int rayCount, void *dst)
+{
+	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
+	if (ctx->poolTD.empty() || bufferIndex < 0 || bufferIndex >= ctx->bufferCount || (which != 0 && which != 1) || !dst) {
+		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "bad buffer selection");
+	}
+	const int W = ctx->resX, H = ctx->resY;
+	const int width = which == 0 ? H : W;
+	const int capacity = which == 0 ? W + 2 * H : 2 * W + H;
+	if (firstRay < 0 || rayCount < 0 || firstRay + rayCount > capacity) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "ray range outside the buffer"); }
+	if (rayCount == 0) { return CVX_OK; }
+	CVX_HIP(ctx, hipSetDevice(ctx->device));
+	const size_t bytes = (size_t)rayCount * (size_t)width * 4;
+	if (bytes > ctx->stagingBytes) {
+		if (ctx->staging) { (void)hipFree(ctx->staging); ctx->staging = nullptr; ctx->stagingBytes = 0; }
+		CVX_HIP(ctx, hipMalloc((void **)&ctx->staging, bytes));
+		ctx->stagingBytes = bytes;
+	}
+	const LastDraw &last = ctx->last[(size_t)bufferIndex];
+	const int s0 = which == 0 ? 0 : 2;
+	const int count0 = last.valid ? (last.segments[s0].RayCount > 0 ? last.segments[s0].RayCount : 0) : capacity;
+	const int tileBase1 = last.valid ? last.tileBase[s0 + 1] : 0;
+	const uint32_t *pool = which == 0 ? ctx->poolTD[(size_t)bufferIndex] : ctx->poolLR[(size_t)bufferIndex];
+	dim3 block(256), grid((unsigned)((width + 255) / 256), (unsigned)rayCount);
+	hipLaunchKernelGGL(cvxk::untile_kernel, grid, block, 0, ctx->stream, pool, ctx->staging, firstRay, rayCount, width, count0, tileBase1,
+	                   which == 0 ? ctx->tilesTD : ctx->tilesLR);
+	CVX_HIP(ctx, hipGetLastError());
+	CVX_HIP(ctx, hipMemcpyAsync(dst, ctx->staging, bytes, hipMemcpyDeviceToHost, ctx->stream));
+	CVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return CVX_OK;
+}
+
+int cvx_blit_segments(cvx_context *ctx, int bufferIndex, void *dstHost)
+{
+	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
+	if (ctx->poolTD.empty() || bufferIndex < 0 || bufferIndex >= ctx->bufferCount) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "bad buffer selection"); }
+	const LastDraw &last = ctx->last[(size_t)bufferIndex];
+	if (!last.valid) { return Fail(ctx, CVX_ERR_NOT_READY, "nothing has been drawn into buffer %d", bufferIndex); }
+	CVX_HIP(ctx, hipSetDevice(ctx->device));
+	cvxk::BlitParams p;
+	p.vpX = last.vp[0];
+	p.vpY = last.vp[1];
+	for (int s = 0; s < 4; s++) {
+		p.minX[s] = last.segments[s].MinScreen[0];
+		p.minY[s] = last.segments[s].MinScreen[1];
+		p.maxX[s] = last.segments[s].MaxScreen[0];
+		p.maxY[s] = last.segments[s].MaxScreen[1];
+		p.rayCount[s] = last.segments[s].RayCount;
+		p.tileBase[s] = last.tileBase[s];
+	}
+	p.width = ctx->resX;
+	p.height = ctx->resY;
+	p.clearColor = 0u;
+	dim3 block(64, 4), grid((unsigned)((p.width + 63) / 64), (unsigned)((p.height + 3) / 4));
+	hipLaunchKernelGGL(cvxk::blit_kernel, grid, block, 0, ctx->stream, ctx->poolTD[(size_t)bufferIndex], ctx->poolLR[(size_t)bufferIndex], ctx->screen, p);
+	CVX_HIP(ctx, hipGetLastError());
+	if (dstHost) {
+		CVX_HIP(ctx, hipMemcpyAsync(dstHost, ctx->screen, (size_t)p.width * (size_t)p.height * 4, hipMemcpyDeviceToHost, ctx->stream));
+		CVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	}
+	return CVX_OK;
+}
+
+int cvx_raybuffer_device_ptr(cvx_context *ctx, int bufferIndex, int which, void **ptr, int64_t *bytes)
+{
+	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
+	if (ctx->poolTD.empty() || bufferIndex < 0 || bufferIndex >= ctx->bufferCount || (which != 0 && which != 1) || !ptr) {
+		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "bad buffer selection");
+	}
+	*ptr = which == 0 ? ctx->poolTD[(size_t)bufferIndex] : ctx->poolLR[(size_t)bufferIndex];
+	if (bytes) { *bytes = (int64_t)(which == 0 ? ctx->poolBytesTD : ctx->poolBytesLR); }
+	return CVX_OK;
+}
+
+int cvx_screen_device_ptr(cvx_context *ctx, void **ptr, int64_t *bytes)
+{
+	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
+	if (!ctx->screen || !ptr) { return Fail(ctx, CVX_ERR_NOT_READY, "resolution not set"); }
+	*ptr = ctx->screen;
+	if (bytes) { *bytes = (int64_t)ctx->resX * ctx->resY * 4; }
+	return CVX_OK;
+}
+
+int cvx_last_draw_ms(cvx_context *ctx, float *ms)
+{
+	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
+	if (!ms) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "ms is NULL"); }
+	CVX_HIP(ctx, hipSetDevice(ctx->device));
+	int rc = FoldEvents(ctx);
+	if (rc != CVX_OK) { return rc; }
+	if (ctx->accumulatedDraws == 0) { return Fail(ctx, CVX_ERR_NOT_READY, "no timed draw yet"); }
+	*ms = ctx->lastMs;
+	return CVX_OK;
+}
+
+int cvx_draw_time_stats(cvx_context *ctx, double *totalMs, int *draws, int reset)
+{
+	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
+	CVX_HIP(ctx, hipSetDevice(ctx->device));
+	int rc = FoldEvents(ctx);
+	if (rc != CVX_OK) { return rc; }
+	if (totalMs) { *totalMs = ctx->accumulatedMs; }
+	if (draws) { *draws = ctx->accumulatedDraws; }
+	if (reset) {
+		ctx->accumulatedMs = 0.0;
+		ctx->accumulatedDraws = 0;
+	}
+	return CVX_OK;
+}
+
+int cvx_enable_counters(cvx_context *ctx, int enable)
+{
+	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
+	ctx->countersEnabled = enable != 0;
+	return CVX_OK;
+}
+
+int cvx_get_counters(cvx_context *ctx, cvx_counters *out)
+{
+	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
+	if (!out) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "out is NULL"); }
+	CVX_HIP(ctx, hipSetDevice(ctx->device));
+	DevCounters c;
+	CVX_HIP(ctx, hipMemcpyAsync(&c, ctx->devCounters, sizeof c, hipMemcpyDeviceToHost, ctx->stream));
+	CVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	out->S = (int64_t)c.S;
+	out->E = (int64_t)c.E;
+	out->C = (int64_t)c.C;
+	out->P = (int64_t)c.P;
+	out->R = (int64_t)c.R;
+	for (int i = 0; i < CVX_LOD_LEVELS; i++) { out->lodVisits[i] = (int64_t)c.lodVisits[i]; }
+	return CVX_OK;
+}
+
+int cvx_get_raybuffer_layout(cvx_context *ctx, int which, cvx_raybuffer_layout *out)
+{
+	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
+	if (!out || (which != 0 && which != 1) || ctx->poolTD.empty()) { return Fail(ctx, CVX_ERR_NOT_READY, "resolution not set"); }
+	const int W = ctx->resX, H = ctx->resY;
+	out->width = which == 0 ? H : W;
+	out->rayCapacity = which == 0 ? W + 2 * H : 2 * W + H;
+	out->tileRays = CVX_WAVE;
+	out->tileCapacity = which == 0 ? ctx->tilesTD : ctx->tilesLR;
+	out->tileBytes = (int64_t)out->width * CVX_WAVE * 4;
+	return CVX_OK;
+}
+
+int cvx_selftest_math(cvx_context *ctx, int op, int n, const float *a, const float *b, float *out)
+{
+	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
+	if (n <= 0 || !a || !b || !out) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "bad arguments"); }
+	CVX_HIP(ctx, hipSetDevice(ctx->device));
+	float *d = nullptr;
+	const size_t bytes = (size_t)n * sizeof(float);
+	CVX_HIP(ctx, hipMalloc((void **)&d, bytes * 3));
+	int rc = CVX_OK;
+	hipError_t e = hipMemcpyAsync(d, a, bytes, hipMemcpyHostToDevice, ctx->stream);
+	if (e == hipSuccess) { e = hipMemcpyAsync(d + n, b, bytes, hipMemcpyHostToDevice, ctx->stream); }
+	if (e == hipSuccess) {
+		hipLaunchKernelGGL(cvxk::selftest_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, op, n, d, d + n, d + 2 * (size_t)n);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) { e = hipMemcpyAsync(out, d + 2 * (size_t)n, bytes, hipMemcpyDeviceToHost, ctx->stream); }
+	if (e == hipSuccess) { e = hipStreamSynchronize(ctx->stream); }
+	if (e != hipSuccess) { rc = Fail(ctx, CVX_ERR_HIP, "selftest failed: %s", hipGetErrorString(e)); }
+	(void)hipFree(d);
+	return rc;
+}
+
+} // extern "C"

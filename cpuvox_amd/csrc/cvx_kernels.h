@@ -1,0 +1,844 @@
+// cvx_kernels.h -- HIP kernels of libcpuvox_gpu (gfx950 / CDNA4, wave64).
+//
+// render kernel: one wavefront (64-thread workgroup) per tile of 64
+// consecutive rays of one segment, one lane per raybuffer column.  It fuses the
+// reference's four Burst jobs (Assets/Code/Rendering/DrawSegmentRayJob.cs):
+//   RaySetupJob :19-39, DDASetupJob :58-76, TraceToFirstColumnJob :95-143,
+//   RenderJob -> ExecuteRay :164-620
+// The per-ray "seen pixel" byte cache (:208) is a per-lane bitmask in LDS,
+// word-interleaved across lanes (word w of lane l at w*64+l: conflict-free);
+// horizon scans (:407-414, :678-692) are ffs/clz over mask words; the skybox
+// fill (:699-716) is deferred to one wave-uniform pass over the pixel rows at
+// the end so its stores are 256-byte coalesced rows of the tile.
+//
+// Arithmetic contract (shared with the CPU oracle, checked by tests): IEEE
+// binary32, no FMA contraction (-ffp-contract=off), correctly rounded / and
+// sqrt, denormals preserved, (int)float with the x86 cvttss2si rule.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "cvx_device.h"
+
+namespace cvxk {
+
+// ---- Unity.Mathematics scalar semantics (math.cs 1.2.6) --------------------
+__device__ __forceinline__ float m_min(float x, float y) { return (y != y || x < y) ? x : y; }
+__device__ __forceinline__ float m_max(float x, float y) { return (y != y || x > y) ? x : y; }
+__device__ __forceinline__ float m_lerp(float a, float b, float t) { return a + t * (b - a); }
+__device__ __forceinline__ float m_sign(float x) { return (x > 0.0f ? 1.0f : 0.0f) - (x < 0.0f ? 1.0f : 0.0f); }
+__device__ __forceinline__ int m_clampi(int x, int a, int b) { return max(a, min(b, x)); }
+
+// C# (int)float compiled by Burst for x86 = cvttss2si: NaN / out of range give
+// INT_MIN.  v_cvt_i32_f32 saturates instead, so the rule is explicit.
+__device__ __forceinline__ int f2i(float x)
+{
+	return (x != x || x >= 2147483648.0f || x < -2147483648.0f) ? (int)0x80000000 : (int)x;
+}
+
+struct f3 {
+	float x, y, z;
+};
+__device__ __forceinline__ f3 f3_madd(f3 a, f3 d, float s) { return { a.x + d.x * s, a.y + d.y * s, a.z + d.z * s }; } // a + d*s
+__device__ __forceinline__ f3 f3_lerp(f3 a, f3 b, float t) { return { a.x + (b.x - a.x) * t, a.y + (b.y - a.y) * t, a.z + (b.z - a.z) * t }; }
+
+#define CVX_FLOAT_EPSILON 1.401298464324817e-45f /* C# float.Epsilon (denormal), DrawSegmentRayJob.cs:220 */
+
+// ---- SegmentDDAData (Assets/Code/Utils/SegmentDDAData.cs) ------------------
+struct DDA {
+	int px, pz;   // position
+	int sx, sz;   // step
+	float startX, startZ, dirX, dirZ, tDeltaX, tDeltaZ, tMaxX, tMaxZ;
+	float distLast, distNext; // intersectionDistances.x / .y
+};
+
+__device__ __forceinline__ void dda_init(DDA &d, float startX, float startZ, float dirX, float dirZ) // :17-28
+{
+	d.startX = startX; d.startZ = startZ; d.dirX = dirX; d.dirZ = dirZ;
+	d.px = f2i(floorf(startX));
+	d.pz = f2i(floorf(startZ));
+	d.tDeltaX = 1.0f / m_max(0.0000001f, fabsf(dirX));
+	d.tDeltaZ = 1.0f / m_max(0.0000001f, fabsf(dirZ));
+	float sgx = m_sign(dirX), sgz = m_sign(dirZ);
+	d.sx = f2i(sgx);
+	d.sz = f2i(sgz);
+	d.tMaxX = (sgx * -(startX - floorf(startX)) + (sgx * 0.5f) + 0.5f) * d.tDeltaX;
+	d.tMaxZ = (sgz * -(startZ - floorf(startZ)) + (sgz * 0.5f) + 0.5f) * d.tDeltaZ;
+	d.distLast = m_max(d.tMaxX - d.tDeltaX, d.tMaxZ - d.tDeltaZ);
+	d.distNext = m_min(d.tMaxX, d.tMaxZ);
+}
+
+__device__ __forceinline__ void dda_next_lod(DDA &d, int currentVoxelSize) // :31-73
+{
+	int remX = d.px & (currentVoxelSize * 2 - 1);
+	int remZ = d.pz & (currentVoxelSize * 2 - 1);
+	float prevX = d.tMaxX - d.tDeltaX;
+	float prevZ = d.tMaxZ - d.tDeltaZ;
+	if ((d.dirX >= 0.0f) == (remX < currentVoxelSize)) { d.tMaxX += d.tDeltaX; } else { prevX -= d.tDeltaX; }
+	if ((d.dirZ >= 0.0f) == (remZ < currentVoxelSize)) { d.tMaxZ += d.tDeltaZ; } else { prevZ -= d.tDeltaZ; }
+	d.distLast = m_max(prevX, prevZ);
+	d.distNext = m_min(d.tMaxX, d.tMaxZ);
+	d.px -= remX;
+	d.pz -= remZ;
+	d.tDeltaX *= 2.0f;
+	d.tDeltaZ *= 2.0f;
+	d.sx *= 2;
+	d.sz *= 2;
+}
+
+__device__ __forceinline__ bool dda_step_to_world_intersection(DDA &d, float dimX, float dimZ) // :75-130
+{
+	const float inf = __builtin_inff();
+	float invX = 1.0f / d.dirX, invZ = 1.0f / d.dirZ;
+	float tminX = -inf, tminZ = -inf, tmaxX = inf, tmaxZ = inf;
+	if (d.dirX != 0.0f) {
+		float t1 = -d.startX * invX;
+		float t2 = (dimX - d.startX) * invX;
+		tminX = m_min(t1, t2);
+		tmaxX = m_max(t1, t2);
+	}
+	if (d.dirZ != 0.0f) {
+		float t1 = -d.startZ * invZ;
+		float t2 = (dimZ - d.startZ) * invZ;
+		tminZ = m_min(t1, t2);
+		tmaxZ = m_max(t1, t2);
+	}
+	float tmint = m_max(tminX, tminZ);
+	float tmaxt = m_min(tmaxX, tmaxZ);
+	if (tmaxt < tmint || tmint <= 0.0f) {
+		return false;
+	}
+	float tLastX, tLastZ;
+	if (tminX < tminZ && tminX != -inf) {
+		tLastZ = tminZ;
+		float hit = d.startX + tmint * d.dirX;
+		hit = d.dirX > 0.0f ? floorf(hit) : ceilf(hit);
+		tLastX = (hit - d.startX) / d.dirX;
+	} else {
+		tLastX = tminX;
+		float hit = d.startZ + tmint * d.dirZ;
+		hit = d.dirZ > 0.0f ? floorf(hit) : ceilf(hit);
+		tLastZ = (hit - d.startZ) / d.dirZ;
+	}
+	d.tMaxX = tLastX + d.tDeltaX;
+	d.tMaxZ = tLastZ + d.tDeltaZ;
+	d.distLast = m_max(tLastX, tLastZ);
+	d.distNext = m_min(d.tMaxX, d.tMaxZ);
+	float mid = m_lerp(d.distLast, d.distNext, 0.5f);
+	d.px = f2i(floorf(d.startX + mid * d.dirX));
+	d.pz = f2i(floorf(d.startZ + mid * d.dirZ));
+	return true;
+}
+
+__device__ __forceinline__ bool dda_step(DDA &d, float farClip) // :135-150
+{
+	float crossed;
+	if (d.tMaxX < d.tMaxZ) {
+		crossed = d.tMaxX;
+		d.tMaxX += d.tDeltaX;
+		d.px += d.sx;
+	} else {
+		crossed = d.tMaxZ;
+		d.tMaxZ += d.tDeltaZ;
+		d.pz += d.sz;
+	}
+	d.distLast = crossed;
+	d.distNext = m_min(d.tMaxX, d.tMaxZ);
+	return crossed >= farClip;
+}
+
+// ---- CameraData helpers (Assets/Code/Utils/CameraData.cs) ------------------
+__device__ __forceinline__ float clip_min(f3 pMin, f3 pMax, float frustum) // :101-107
+{
+	float finv = 1.0f / frustum;
+	float c0 = 1.0f * pMax.z - finv * pMax.x;
+	float c1 = 1.0f * pMin.z - finv * pMin.x;
+	return 1.0f - (c0 / (c0 - c1));
+}
+__device__ __forceinline__ float clip_max(f3 pMin, f3 pMax, float frustum) // :109-115
+{
+	float finv = 1.0f / frustum;
+	float c0 = 1.0f * pMax.z - finv * pMax.x;
+	float c1 = 1.0f * pMin.z - finv * pMin.x;
+	return c1 / (c1 - c0);
+}
+
+// GetWorldBoundsClippingCamSpace, :51-99.  true = entirely outside.
+__device__ __forceinline__ bool clip_world_bounds(f3 pMin, f3 pMax, float fMin, float fMax, float &minLerp, float &maxLerp)
+{
+	minLerp = 0.0f;
+	maxLerp = 1.0f;
+	if (pMin.x > pMin.z * fMax) {
+		if (pMax.x > pMax.z * fMax) {
+			return true;
+		}
+		minLerp = clip_min(pMin, pMax, fMax);
+		if (pMax.x < pMax.z * fMin) {
+			maxLerp = clip_max(pMin, pMax, fMin);
+		}
+	} else if (pMax.x > pMax.z * fMax) {
+		maxLerp = clip_max(pMin, pMax, fMax);
+		if (pMin.x < pMin.z * fMin) {
+			minLerp = clip_min(pMin, pMax, fMin);
+		}
+	} else {
+		if (pMin.x < pMin.z * fMin) {
+			if (pMax.x < pMax.z * fMin) {
+				return true;
+			}
+			minLerp = clip_min(pMin, pMax, fMin);
+		} else if (pMax.x < pMax.z * fMin) {
+			maxLerp = clip_max(pMin, pMax, fMin);
+		}
+	}
+	return false;
+}
+
+// ---- seen-pixel bitmask in LDS ---------------------------------------------
+// first unseen pixel >= start, or omax+1; start unchanged when start > omax
+// (the reference's while loop at :407 / :678 does not run then).
+__device__ __forceinline__ int scan_up(const uint32_t *seen, int start, int omax)
+{
+	if (start > omax) {
+		return start;
+	}
+	int w = start >> 5;
+	const int wend = omax >> 5;
+	uint32_t m = ~seen[w * CVX_WAVE] & (0xFFFFFFFFu << (start & 31));
+	while (m == 0u && w < wend) {
+		w++;
+		m = ~seen[w * CVX_WAVE];
+	}
+	if (m == 0u) {
+		return omax + 1;
+	}
+	int pos = (w << 5) + (__ffs((int)m) - 1);
+	return pos > omax ? omax + 1 : pos;
+}
+
+// last unseen pixel <= start, or omin-1; start unchanged when start < omin (:413 / :690).
+__device__ __forceinline__ int scan_down(const uint32_t *seen, int start, int omin)
+{
+	if (start < omin) {
+		return start;
+	}
+	int w = start >> 5;
+	const int wbeg = omin >> 5;
+	uint32_t m = ~seen[w * CVX_WAVE] & (0xFFFFFFFFu >> (31 - (start & 31)));
+	while (m == 0u && w > wbeg) {
+		w--;
+		m = ~seen[w * CVX_WAVE];
+	}
+	if (m == 0u) {
+		return omin - 1;
+	}
+	int pos = (w << 5) + (31 - __clz((int)m));
+	return pos < omin ? omin - 1 : pos;
+}
+
+// bits of word w that fall inside [lo, hi]
+__device__ __forceinline__ uint32_t range_mask(int w, int lo, int hi)
+{
+	int base = w << 5;
+	uint32_t m = 0xFFFFFFFFu;
+	if (lo > base) { m &= 0xFFFFFFFFu << (lo - base); }
+	if (hi < base + 31) { m &= 0xFFFFFFFFu >> (base + 31 - hi); }
+	return m;
+}
+
+// ReducePixelHorizon, DrawSegmentRayJob.cs:660-697
+__device__ __forceinline__ void reduce_pixel_horizon(const uint32_t *seen, int omin, int omax, int &rbMin, int &rbMax, int &nfMin, int &nfMax,
+                                                     float &frustumBoundsMin, float &frustumBoundsMax)
+{
+	if (rbMin <= nfMin) {
+		rbMin = nfMin;
+		if (rbMax >= nfMin) {
+			nfMin = scan_up(seen, rbMax + 1, omax);
+			frustumBoundsMin = (float)nfMin - 0.501f;
+		}
+	}
+	if (rbMax >= nfMax) {
+		rbMax = nfMax;
+		if (rbMin <= nfMax) {
+			nfMax = scan_down(seen, rbMin - 1, omin);
+			frustumBoundsMax = (float)nfMax + 0.501f;
+		}
+	}
+}
+
+struct LaneCounters {
+	unsigned int S, E, C, P;
+	unsigned int lod[6];
+};
+
+// ---------------------------------------------------------------------------
+// One ray: TraceToFirstColumnJob + ExecuteRay.  Writes colour pixels to
+// out[y*64] and marks them in seen[]; every exit path of the reference ends in
+// WriteSkybox/WriteSkyboxFull, which the caller performs for the whole wave.
+// ---------------------------------------------------------------------------
+template <int DIR, bool COUNT>
+__device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S, const DevWorld *__restrict__ world, int planeRayIndex,
+                                          uint32_t *seen /* &lds[lane] */, uint32_t *out /* tile + lane */, LaneCounters &cnt)
+{
+	const int omin = S.omin, omax = S.omax;
+	const float farClip = F.farClip;
+	const float posY = F.posY;
+
+	// ---- DDASetupJob.Execute, :58-76
+	DDA ray;
+	{
+		float endRayLerp = (float)planeRayIndex / (float)S.rayCount;
+		float dx = m_lerp(S.rayMinX, S.rayMaxX, endRayLerp);
+		float dz = m_lerp(S.rayMinZ, S.rayMaxZ, endRayLerp);
+		float r = 1.0f / sqrtf(dx * dx + dz * dz); // math.normalize = rsqrt(dot) * v, rsqrt = 1/sqrt
+		dda_init(ray, F.posX, F.posZ, r * dx, r * dz);
+	}
+
+	// ---- TraceToFirstColumnJob.Execute, :95-143
+	int lod = 0;
+	float lodMax = F.lod[0];
+	const int dimX = world->dimX, dimZ = world->dimZ;
+	if (ray.px < 0 || ray.pz < 0 || ray.px >= dimX || ray.pz >= dimZ) {
+		if (!dda_step_to_world_intersection(ray, (float)dimX, (float)dimZ)) {
+			return; // WriteSkyboxFull
+		}
+		while (ray.distLast >= lodMax && lod < 5) { // lod < 5: memory-safety guard only, such a ray is beyond far clip anyway
+			dda_next_lod(ray, 1 << lod);
+			lod++;
+			lodMax = F.lod[lod];
+		}
+		if (m_min(ray.tMaxX, ray.tMaxZ) >= farClip) { // IsBeyondFarClip, SegmentDDAData.cs:152
+			return; // WriteSkyboxFull
+		}
+	}
+
+	// ---- ExecuteRay, :195-620
+	int voxelScale = 1 << lod;
+	DevWorldLevel L = world->level[lod];
+	const int maskX = world->maskX, maskZ = world->maskZ;
+	const float worldMaxY = (float)world->dimY;
+	const float cameraPosYNormalized = posY / worldMaxY;
+
+	int nextFreePixelMin = omin;
+	int nextFreePixelMax = omax;
+	float frustumBoundsMin = (float)nextFreePixelMin - 0.501f;
+	float frustumBoundsMax = (float)nextFreePixelMax + 0.501f;
+	float frustumDirMaxWorld = CVX_FLOAT_EPSILON;
+	float frustumDirMinWorld = CVX_FLOAT_EPSILON;
+
+	// SetupProjectedPlaneParams, :622-651: rows (x or y), z, w of M applied to
+	// (start.x, 0 | worldMaxY, start.z, 1) and (dir.x, 0, dir.z, 0).
+	f3 planeStartBottom, planeStartTop, planeDir;
+	{
+		const float *M = F.M;
+		const int r0 = S.axisMappedToY ? 1 : 0;
+		const float sx = ray.startX, sz = ray.startZ;
+		// mul(float4x4, float4) = c0*x + c1*y + c2*z + c3*w, left to right
+		planeStartTop.x = M[0 + r0] * sx + M[4 + r0] * worldMaxY + M[8 + r0] * sz + M[12 + r0] * 1.0f;
+		planeStartTop.y = M[2] * sx + M[6] * worldMaxY + M[10] * sz + M[14] * 1.0f;
+		planeStartTop.z = M[3] * sx + M[7] * worldMaxY + M[11] * sz + M[15] * 1.0f;
+		planeStartBottom.x = M[0 + r0] * sx + M[4 + r0] * 0.0f + M[8 + r0] * sz + M[12 + r0] * 1.0f;
+		planeStartBottom.y = M[2] * sx + M[6] * 0.0f + M[10] * sz + M[14] * 1.0f;
+		planeStartBottom.z = M[3] * sx + M[7] * 0.0f + M[11] * sz + M[15] * 1.0f;
+		planeDir.x = M[0 + r0] * ray.dirX + M[4 + r0] * 0.0f + M[8 + r0] * ray.dirZ + M[12 + r0] * 0.0f;
+		planeDir.y = M[2] * ray.dirX + M[6] * 0.0f + M[10] * ray.dirZ + M[14] * 0.0f;
+		planeDir.z = M[3] * ray.dirX + M[7] * 0.0f + M[11] * ray.dirZ + M[15] * 0.0f;
+	}
+
+	// A DDA walk is monotone in x and z, so it leaves the world after at most
+	// dimX + dimZ column visits; the cap can never bind on valid input and only
+	// keeps a wave from spinning on non-finite camera data.
+	for (int guardSteps = dimX + dimZ + 16; guardSteps > 0; guardSteps--) {
+		if (ray.distLast >= lodMax && lod < 5) { // :237-243
+			dda_next_lod(ray, voxelScale);
+			lod++;
+			voxelScale *= 2;
+			L = world->level[lod];
+			lodMax = F.lod[lod];
+		}
+
+		// World.GetVoxelColumn, World.cs:130-142
+		if ((ray.px & maskX) != ray.px || (ray.pz & maskZ) != ray.pz) {
+			return; // out of world bounds -> WriteSkybox
+		}
+		const uint4 header = L.headers[(ray.px >> L.shift) * L.mulX + (ray.pz >> L.shift)];
+		const int columnRuns = (int)(header.y & 0xFFFFu);
+		if (COUNT) {
+			cnt.S++;
+#pragma unroll
+			for (int k = 0; k < 6; k++) { cnt.lod[k] += (lod == k) ? 1u : 0u; }
+		}
+		if (columnRuns == 0) {
+			if (dda_step(ray, farClip)) {
+				return;
+			}
+			continue;
+		}
+		const float columnWorldMin = (float)(header.y >> 16);
+		const float columnWorldMax = (float)(header.z & 0xFFFFu);
+
+		float worldBoundsMin = 0.0f;
+		float worldBoundsMax = worldMaxY;
+
+		if (frustumDirMaxWorld != CVX_FLOAT_EPSILON) { // :261-281
+			float distTop = frustumDirMaxWorld > 0.0f ? ray.distNext : ray.distLast;
+			float distBot = frustumDirMinWorld < 0.0f ? ray.distNext : ray.distLast;
+			float newMax = posY + frustumDirMaxWorld * distTop;
+			float newMin = posY + frustumDirMinWorld * distBot;
+			if (newMin > worldBoundsMax || newMax < worldBoundsMin) {
+				return;
+			}
+			if (columnWorldMin > newMax || columnWorldMax < newMin) {
+				if (dda_step(ray, farClip)) {
+					return;
+				}
+				continue;
+			}
+			worldBoundsMin = newMin;
+			worldBoundsMax = newMax;
+		}
+
+		// :289-293
+		const f3 camSpaceMinLast = f3_madd(planeStartBottom, planeDir, ray.distLast);
+		const f3 camSpaceMinNext = f3_madd(planeStartBottom, planeDir, ray.distNext);
+		const f3 camSpaceMaxLast = f3_madd(planeStartTop, planeDir, ray.distLast);
+		const f3 camSpaceMaxNext = f3_madd(planeStartTop, planeDir, ray.distNext);
+
+		if (ray.distLast > 2.0f && frustumDirMaxWorld == CVX_FLOAT_EPSILON) { // :295-422
+			float clipLastMinLerp, clipLastMaxLerp, clipNextMinLerp, clipNextMaxLerp;
+			const bool clippedLast = clip_world_bounds(camSpaceMinLast, camSpaceMaxLast, frustumBoundsMin, frustumBoundsMax, clipLastMinLerp, clipLastMaxLerp);
+			const bool clippedNext = clip_world_bounds(camSpaceMinNext, camSpaceMaxNext, frustumBoundsMin, frustumBoundsMax, clipNextMinLerp, clipNextMaxLerp);
+
+			float camSpaceClippedMin, camSpaceClippedMax;
+			if (clippedLast) {
+				if (clippedNext) {
+					return;
+				}
+				worldBoundsMin = m_lerp(0.0f, worldMaxY, clipNextMinLerp);
+				worldBoundsMax = m_lerp(0.0f, worldMaxY, clipNextMaxLerp);
+				frustumDirMaxWorld = (worldBoundsMax - posY) / ray.distNext;
+				frustumDirMinWorld = (worldBoundsMin - posY) / ray.distNext;
+				f3 minClip = f3_lerp(camSpaceMinNext, camSpaceMaxNext, clipNextMinLerp);
+				f3 maxClip = f3_lerp(camSpaceMinNext, camSpaceMaxNext, clipNextMaxLerp);
+				camSpaceClippedMin = minClip.x / minClip.z;
+				camSpaceClippedMax = maxClip.x / maxClip.z;
+				if (camSpaceClippedMax < camSpaceClippedMin) {
+					float t = camSpaceClippedMin; camSpaceClippedMin = camSpaceClippedMax; camSpaceClippedMax = t;
+				}
+			} else if (clippedNext) {
+				worldBoundsMin = m_lerp(0.0f, worldMaxY, clipLastMinLerp);
+				worldBoundsMax = m_lerp(0.0f, worldMaxY, clipLastMaxLerp);
+				f3 minClip = f3_lerp(camSpaceMinLast, camSpaceMaxLast, clipLastMinLerp);
+				f3 maxClip = f3_lerp(camSpaceMinLast, camSpaceMaxLast, clipLastMaxLerp);
+				frustumDirMaxWorld = (worldBoundsMax - posY) / ray.distLast;
+				frustumDirMinWorld = (worldBoundsMin - posY) / ray.distLast;
+				camSpaceClippedMin = minClip.x / minClip.z;
+				camSpaceClippedMax = maxClip.x / maxClip.z;
+				if (camSpaceClippedMax < camSpaceClippedMin) {
+					float t = camSpaceClippedMin; camSpaceClippedMin = camSpaceClippedMax; camSpaceClippedMax = t;
+				}
+			} else {
+				if (clipLastMinLerp < clipNextMinLerp) {
+					worldBoundsMin = m_lerp(0.0f, worldMaxY, clipLastMinLerp);
+					frustumDirMinWorld = (worldBoundsMin - posY) / ray.distLast;
+				} else {
+					worldBoundsMin = m_lerp(0.0f, worldMaxY, clipNextMinLerp);
+					frustumDirMinWorld = (worldBoundsMin - posY) / ray.distNext;
+				}
+				if (clipLastMaxLerp > clipNextMaxLerp) {
+					worldBoundsMax = m_lerp(0.0f, worldMaxY, clipLastMaxLerp);
+					frustumDirMaxWorld = (worldBoundsMax - posY) / ray.distLast;
+				} else {
+					worldBoundsMax = m_lerp(0.0f, worldMaxY, clipNextMaxLerp);
+					frustumDirMaxWorld = (worldBoundsMax - posY) / ray.distNext;
+				}
+				f3 minClipA = f3_lerp(camSpaceMinLast, camSpaceMaxLast, clipLastMinLerp);
+				f3 maxClipA = f3_lerp(camSpaceMinLast, camSpaceMaxLast, clipLastMaxLerp);
+				f3 minClipB = f3_lerp(camSpaceMinNext, camSpaceMaxNext, clipNextMinLerp);
+				f3 maxClipB = f3_lerp(camSpaceMinNext, camSpaceMaxNext, clipNextMaxLerp);
+				float minNext = minClipB.x / minClipB.z;
+				float minLast = minClipA.x / minClipA.z;
+				float maxNext = maxClipB.x / maxClipB.z;
+				float maxLast = maxClipA.x / maxClipA.z;
+				if (maxNext < minNext) { float t = maxNext; maxNext = minNext; minNext = t; }
+				if (maxLast < minLast) { float t = maxLast; maxLast = minLast; minLast = t; }
+				camSpaceClippedMin = m_min(minLast, minNext);
+				camSpaceClippedMax = m_max(maxLast, maxNext);
+			}
+
+			worldBoundsMin = floorf(worldBoundsMin);
+			worldBoundsMax = ceilf(worldBoundsMax);
+
+			const int writableMinPixel = f2i(floorf(camSpaceClippedMin));
+			const int writableMaxPixel = f2i(ceilf(camSpaceClippedMax));
+
+			if (writableMaxPixel < nextFreePixelMin || writableMinPixel > nextFreePixelMax) {
+				return;
+			}
+			if (writableMinPixel > nextFreePixelMin) {
+				nextFreePixelMin = scan_up(seen, writableMinPixel, omax);
+			}
+			if (writableMaxPixel < nextFreePixelMax) {
+				nextFreePixelMax = scan_down(seen, writableMaxPixel, omin);
+			}
+			if (nextFreePixelMin > nextFreePixelMax) {
+				return;
+			}
+		}
+
+		// ---- element loop, :424-611
+		float elementBoundsMin, elementBoundsMax;
+		const uint32_t *guardStart = L.elements + header.x; // RLEColumn.ElementGuardStart, World.cs:175
+		const uint32_t *elementPointer;
+		if (DIR > 0) {
+			elementBoundsMin = worldMaxY;
+			elementBoundsMax = worldMaxY;
+			elementPointer = guardStart;
+		} else {
+			elementBoundsMin = 0.0f;
+			elementBoundsMax = 0.0f;
+			elementPointer = guardStart + columnRuns + 1; // ElementGuardEnd, World.cs:180
+		}
+		const uint32_t *worldColumnColors = guardStart + columnRuns + 2; // ColorPointer, World.cs:185
+
+		while (true) {
+			elementPointer += DIR;
+			const uint32_t raw = *elementPointer;
+			const int elementColorsIndex = (int)(short)(raw & 0xFFFFu);
+			const int elementLength = (int)(short)(raw >> 16);
+			if (COUNT) { cnt.E++; }
+			if (elementLength == 0) {
+				break;
+			}
+
+			if (DIR > 0) {
+				elementBoundsMax = elementBoundsMin;
+				elementBoundsMin = elementBoundsMin - (float)(elementLength * voxelScale);
+			} else {
+				elementBoundsMin = elementBoundsMax;
+				elementBoundsMax = elementBoundsMin + (float)(elementLength * voxelScale);
+			}
+
+			if (elementColorsIndex < 0) {
+				continue;
+			}
+			if (elementBoundsMin > worldBoundsMax) {
+				if (DIR < 0) { break; } else { continue; }
+			}
+			if (elementBoundsMax < worldBoundsMin) {
+				if (DIR > 0) { break; } else { continue; }
+			}
+
+			const float portionBottom = (elementBoundsMin - 0.0f) / (worldMaxY - 0.0f); // unlerp(0, worldMaxY, x)
+			const float portionTop = (elementBoundsMax - 0.0f) / (worldMaxY - 0.0f);
+			f3 camSpaceFrontBottom = f3_lerp(camSpaceMinLast, camSpaceMaxLast, portionBottom);
+			f3 camSpaceFrontTop = f3_lerp(camSpaceMinLast, camSpaceMaxLast, portionTop);
+
+			// side of the run, :484-542
+			{
+				float uA = (float)elementLength;
+				float uB = 0.0f;
+				bool visible = true; // ClipHomogeneousCameraSpaceLine with u, CameraData.cs:141-157
+				if (camSpaceFrontBottom.y <= 0.0f) {
+					if (camSpaceFrontTop.y <= 0.0f) {
+						visible = false;
+					} else {
+						float v = camSpaceFrontTop.y / (camSpaceFrontTop.y - camSpaceFrontBottom.y);
+						camSpaceFrontBottom = f3_lerp(camSpaceFrontTop, camSpaceFrontBottom, v);
+						uA = m_lerp(uB, uA, v);
+					}
+				} else if (camSpaceFrontTop.y <= 0.0f) {
+					float v = camSpaceFrontBottom.y / (camSpaceFrontBottom.y - camSpaceFrontTop.y);
+					camSpaceFrontTop = f3_lerp(camSpaceFrontBottom, camSpaceFrontTop, v);
+					uB = m_lerp(uA, uB, v);
+				}
+				if (visible) {
+					float uvAx = 1.0f / camSpaceFrontBottom.z, uvAy = uA / camSpaceFrontBottom.z;
+					float uvBx = 1.0f / camSpaceFrontTop.z, uvBy = uB / camSpaceFrontTop.z;
+					float boundsX = camSpaceFrontBottom.x / camSpaceFrontBottom.z; // ProjectClippedToScreen, CameraData.cs:160
+					float boundsY = camSpaceFrontTop.x / camSpaceFrontTop.z;
+					if (boundsX > boundsY) {
+						float t = boundsX; boundsX = boundsY; boundsY = t;
+						t = uvAx; uvAx = uvBx; uvBx = t;
+						t = uvAy; uvAy = uvBy; uvBy = t;
+					}
+					int rbMin = f2i(rintf(boundsX));
+					int rbMax = f2i(rintf(boundsY));
+					if (rbMax >= nextFreePixelMin && rbMin <= nextFreePixelMax) {
+						reduce_pixel_horizon(seen, omin, omax, rbMin, rbMax, nextFreePixelMin, nextFreePixelMax, frustumBoundsMin, frustumBoundsMax);
+						for (int w = rbMin >> 5; w <= (rbMax >> 5); w++) { // pixel loop :519-533 over unseen bits
+							const uint32_t range = range_mask(w, rbMin, rbMax);
+							const uint32_t m = seen[w * CVX_WAVE];
+							uint32_t todo = ~m & range;
+							if (todo != 0u) {
+								seen[w * CVX_WAVE] = m | range;
+								frustumDirMaxWorld = CVX_FLOAT_EPSILON;
+								do {
+									const int y = (w << 5) + (__ffs((int)todo) - 1);
+									todo &= todo - 1u;
+									float l = ((float)y - boundsX) / (boundsY - boundsX); // unlerp
+									float wux = m_lerp(uvAx, uvBx, l);
+									float wuy = m_lerp(uvAy, uvBy, l);
+									float u = wuy / wux;
+									int colorIdx = m_clampi(f2i(floorf(u)), 0, elementLength - 1) + elementColorsIndex;
+									out[y * CVX_WAVE] = worldColumnColors[colorIdx];
+									if (COUNT) { cnt.C++; cnt.P++; }
+								} while (todo != 0u);
+							}
+						}
+						if (nextFreePixelMin > nextFreePixelMax) {
+							return;
+						}
+					}
+				}
+			}
+
+			// top / bottom of the run, :544-610
+			f3 secA, secB;
+			uint32_t secondaryColor;
+			if (portionTop < cameraPosYNormalized) {
+				if (elementBoundsMax > worldBoundsMax) {
+					continue;
+				}
+				secondaryColor = worldColumnColors[elementColorsIndex];
+				if (COUNT) { cnt.C++; }
+				secA = f3_lerp(camSpaceMinNext, camSpaceMaxNext, portionTop);
+				secB = camSpaceFrontTop;
+			} else if (portionBottom > cameraPosYNormalized) {
+				if (elementBoundsMin < worldBoundsMin) {
+					continue;
+				}
+				secondaryColor = worldColumnColors[elementColorsIndex + elementLength - 1];
+				if (COUNT) { cnt.C++; }
+				secA = f3_lerp(camSpaceMinNext, camSpaceMaxNext, portionBottom);
+				secB = camSpaceFrontBottom;
+			} else {
+				continue;
+			}
+
+			bool visible = true; // ClipHomogeneousCameraSpaceLine, CameraData.cs:124-138
+			if (secA.y <= 0.0f) {
+				if (secB.y <= 0.0f) {
+					visible = false;
+				} else {
+					float v = secB.y / (secB.y - secA.y);
+					secA = f3_lerp(secB, secA, v);
+				}
+			} else if (secB.y <= 0.0f) {
+				float v = secA.y / (secA.y - secB.y);
+				secB = f3_lerp(secA, secB, v);
+			}
+			if (visible) {
+				float bx = rintf(secA.x / secA.z);
+				float by = rintf(secB.x / secB.z);
+				int rbMin = f2i(bx);
+				int rbMax = f2i(by);
+				if (rbMin > rbMax) {
+					int t = rbMin; rbMin = rbMax; rbMax = t;
+				}
+				if (rbMax >= nextFreePixelMin && rbMin <= nextFreePixelMax) {
+					reduce_pixel_horizon(seen, omin, omax, rbMin, rbMax, nextFreePixelMin, nextFreePixelMax, frustumBoundsMin, frustumBoundsMax);
+					for (int w = rbMin >> 5; w <= (rbMax >> 5); w++) { // :595-603
+						const uint32_t range = range_mask(w, rbMin, rbMax);
+						const uint32_t m = seen[w * CVX_WAVE];
+						uint32_t todo = ~m & range;
+						if (todo != 0u) {
+							seen[w * CVX_WAVE] = m | range;
+							frustumDirMaxWorld = CVX_FLOAT_EPSILON;
+							do {
+								const int y = (w << 5) + (__ffs((int)todo) - 1);
+								todo &= todo - 1u;
+								out[y * CVX_WAVE] = secondaryColor;
+								if (COUNT) { cnt.P++; }
+							} while (todo != 0u);
+						}
+					}
+					if (nextFreePixelMin > nextFreePixelMax) {
+						return;
+					}
+				}
+			}
+		}
+
+		if (dda_step(ray, farClip)) {
+			return;
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------
+// render kernel: grid = tiles, block = 64 (one wave).  LDS: words*64 uint32.
+// ---------------------------------------------------------------------------
+template <int DIR, bool COUNT>
+__global__ __launch_bounds__(CVX_WAVE) void render_kernel(const DevFrame *__restrict__ frames, const DevTile *__restrict__ tiles,
+                                                          const DevWorld *__restrict__ world, DevCounters *__restrict__ counters)
+{
+	extern __shared__ uint32_t lds[];
+	const int lane = threadIdx.x;
+	const DevTile tile = tiles[blockIdx.x];
+	const DevFrame &F = frames[tile.frame];
+	const DevSegment &S = F.seg[tile.seg];
+
+	const int colLen = S.colLen;
+	const int words = (colLen + 31) >> 5;
+	for (int w = 0; w < words; w++) {
+		lds[w * CVX_WAVE + lane] = 0u; // stackalloc is zero-initialised, :208
+	}
+
+	// RaySetupJob (:19-39): tile -> (segment, planeRayIndex)
+	const int planeRayIndex = tile.tileInSeg * CVX_WAVE + lane;
+	const bool active = planeRayIndex < S.rayCount;
+	uint32_t *pool = tile.seg < 2 ? F.poolTD : F.poolLR;
+	uint32_t *out = pool + ((size_t)(S.tileBase + tile.tileInSeg) * (size_t)colLen) * CVX_WAVE + lane;
+	uint32_t *seen = lds + lane;
+
+	LaneCounters cnt;
+	if (COUNT) {
+		cnt.S = cnt.E = cnt.C = cnt.P = 0;
+		for (int i = 0; i < 6; i++) { cnt.lod[i] = 0; }
+	}
+
+	if (active) {
+		trace_ray<DIR, COUNT>(F, S, world, planeRayIndex, seen, out, cnt);
+	}
+
+	// WriteSkybox / WriteSkyboxFull (:699-716) for the whole wave: every pixel
+	// of [omin, omax] not marked seen gets the skybox colour.
+	const int omin = S.omin, omax = S.omax;
+	unsigned int skyPixels = 0;
+	for (int w = omin >> 5; w <= (omax >> 5); w++) {
+		uint32_t todo = ~seen[w * CVX_WAVE] & range_mask(w, omin, omax);
+		if (!active) { todo = 0u; }
+		const int base = w << 5;
+#pragma unroll 4
+		for (int b = 0; b < 32; b++) {
+			if ((todo >> b) & 1u) {
+				out[(base + b) * CVX_WAVE] = CVX_SKYBOX_ARGB;
+			}
+		}
+		if (COUNT) { skyPixels += (unsigned int)__popc(todo); }
+	}
+
+	if (COUNT) {
+		cnt.P += skyPixels;
+		atomicAdd(&counters->S, (unsigned long long)cnt.S);
+		atomicAdd(&counters->E, (unsigned long long)cnt.E);
+		atomicAdd(&counters->C, (unsigned long long)cnt.C);
+		atomicAdd(&counters->P, (unsigned long long)cnt.P);
+		atomicAdd(&counters->R, active ? 1ull : 0ull);
+		for (int i = 0; i < 6; i++) {
+			atomicAdd(&counters->lodVisits[i], (unsigned long long)cnt.lod[i]);
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------
+// untile: tile-major pool -> the reference's ray-major rows (RayBuffer.cs:121-128)
+// rows [firstRay, firstRay+rayCount) of buffer `which`; count0 = RayCount of the
+// pool's first segment (segment 0 or 2), tileBase1 = first tile of the second.
+// ---------------------------------------------------------------------------
+__global__ void untile_kernel(const uint32_t *__restrict__ pool, uint32_t *__restrict__ dst, int firstRay, int rayCount, int width,
+                              int count0, int tileBase1, int tileCapacity)
+{
+	const int y = blockIdx.x * blockDim.x + threadIdx.x;
+	const int row = blockIdx.y;
+	if (y >= width || row >= rayCount) {
+		return;
+	}
+	const int r = firstRay + row;
+	int plane, tileBase;
+	if (r < count0) {
+		plane = r;
+		tileBase = 0;
+	} else {
+		plane = r - count0;
+		tileBase = tileBase1;
+	}
+	const int tile = tileBase + (plane >> 6);
+	uint32_t v = 0u;
+	if (tile < tileCapacity) {
+		v = pool[((size_t)tile * (size_t)width + (size_t)y) * CVX_WAVE + (plane & 63)];
+	}
+	dst[(size_t)row * (size_t)width + (size_t)y] = v;
+}
+
+// ---------------------------------------------------------------------------
+// Phase 2: RenderManager.BlitSegments (RenderManager.cs:199-256) +
+// RayBufferBlit.shader frag (:48-64), evaluated at pixel centres.  Rule (ours,
+// Unity's rasteriser is not restated): barycentrics of the centre in triangle
+// (VP, MaxScreen, MinScreen); first segment whose weights are all >= 0 wins;
+// x = wMax / (wMax + wMin); ray = clamp(floor(x * RayCount), 0, RayCount-1).
+// ---------------------------------------------------------------------------
+struct BlitParams {
+	float vpX, vpY;
+	float minX[4], minY[4], maxX[4], maxY[4];
+	int rayCount[4];
+	int tileBase[4];
+	int width, height;
+	uint32_t clearColor;
+};
+
+__global__ void blit_kernel(const uint32_t *__restrict__ poolTD, const uint32_t *__restrict__ poolLR, uint32_t *__restrict__ screen, BlitParams p)
+{
+	const int px = blockIdx.x * blockDim.x + threadIdx.x;
+	const int py = blockIdx.y * blockDim.y + threadIdx.y;
+	if (px >= p.width || py >= p.height) {
+		return;
+	}
+	const float cx = (float)px + 0.5f, cy = (float)py + 0.5f;
+	uint32_t color = p.clearColor;
+	for (int s = 0; s < 4; s++) {
+		const int rc = p.rayCount[s];
+		if (rc <= 0) {
+			continue;
+		}
+		const float ax = p.vpX, ay = p.vpY, bx = p.maxX[s], by = p.maxY[s], qx = p.minX[s], qy = p.minY[s];
+		const float den = (by - qy) * (ax - qx) + (qx - bx) * (ay - qy);
+		const float wVp = ((by - qy) * (cx - qx) + (qx - bx) * (cy - qy)) / den;
+		const float wMax = ((qy - ay) * (cx - qx) + (ax - qx) * (cy - qy)) / den;
+		const float wMin = 1.0f - wVp - wMax;
+		if (wVp >= 0.0f && wMax >= 0.0f && wMin >= 0.0f) {
+			const float x = wMax / (wMax + wMin);
+			float rf = floorf(x * (float)rc);
+			rf = fminf(fmaxf(rf, 0.0f), (float)(rc - 1));
+			const int ray = (rf == rf) ? (int)rf : 0;
+			const int tile = p.tileBase[s] + (ray >> 6);
+			if (s < 2) {
+				color = poolTD[((size_t)tile * (size_t)p.height + (size_t)py) * CVX_WAVE + (ray & 63)];
+			} else {
+				color = poolLR[((size_t)tile * (size_t)p.width + (size_t)px) * CVX_WAVE + (ray & 63)];
+			}
+			break;
+		}
+	}
+	screen[(size_t)py * (size_t)p.width + (size_t)px] = color;
+}
+
+// ---------------------------------------------------------------------------
+// arithmetic self-test (cvx_selftest_math): pins the device float contract.
+// ---------------------------------------------------------------------------
+__global__ void selftest_math_kernel(int op, int n, const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= n) {
+		return;
+	}
+	const float x = a[i], y = b[i];
+	float r;
+	switch (op) {
+	case 0: r = x / y; break;
+	case 1: r = sqrtf(x); break;
+	case 2: r = 1.0f / sqrtf(x); break;
+	case 3: r = x + y * (y - x); break;
+	case 4: r = floorf(x); break;
+	case 5: r = ceilf(x); break;
+	case 6: r = rintf(x); break;
+	case 7: r = __int_as_float(f2i(x)); break;
+	case 8: r = x * y; break;
+	case 9: r = x + y; break;
+	default: r = 0.0f; break;
+	}
+	out[i] = r;
+}
+
+} // namespace cvxk

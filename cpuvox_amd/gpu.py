@@ -1,0 +1,261 @@
+"""ctypes binding of libcpuvox_gpu.so (include/cpuvox_gpu.h): the C-ABI
+drop-in for RenderManager.DrawSegments (Assets/Code/RenderManager.cs:258-372)
+running as HIP kernels on MI355X.
+
+There is NO CPU fallback: if the library or a HIP device is missing every
+call raises.  (The CPU oracle lives under oracle/ and is test infrastructure;
+this package never imports it.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .host import CameraData, Frame, LOD_LEVELS, SegmentData, WorldSet
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+RAYBUFFER_TOPDOWN = 0
+RAYBUFFER_LEFTRIGHT = 1
+DRAW_SYNC = 0
+DRAW_ASYNC = 1
+
+# every symbol include/cpuvox_gpu.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "cvx_create", "cvx_destroy", "cvx_last_error", "cvx_set_stream", "cvx_world_upload", "cvx_set_resolution",
+    "cvx_set_buffer_count", "cvx_draw_segments", "cvx_draw_segments_batch", "cvx_set_shard", "cvx_synchronize",
+    "cvx_clear_raybuffer", "cvx_read_raybuffer", "cvx_blit_segments", "cvx_raybuffer_device_ptr",
+    "cvx_screen_device_ptr", "cvx_last_draw_ms", "cvx_enable_counters", "cvx_get_counters",
+    "cvx_get_raybuffer_layout", "cvx_selftest_math", "cvx_version", "cvx_bind_raybuffers", "cvx_draw_time_stats",
+]
+
+
+class Counters(C.Structure):
+    _fields_ = [("S", C.c_int64), ("E", C.c_int64), ("C", C.c_int64), ("P", C.c_int64), ("R", C.c_int64),
+                ("lodVisits", C.c_int64 * LOD_LEVELS)]
+
+    def algorithmic_bytes(self) -> int:
+        return 12 * self.S + 4 * self.E + 4 * self.C + 4 * self.P + 80 * self.R
+
+    def as_dict(self):
+        return {"S": self.S, "E": self.E, "C": self.C, "P": self.P, "R": self.R,
+                "lodVisits": list(self.lodVisits), "bytes": self.algorithmic_bytes()}
+
+
+class RaybufferLayout(C.Structure):
+    _fields_ = [("width", C.c_int32), ("rayCapacity", C.c_int32), ("tileRays", C.c_int32),
+                ("tileCapacity", C.c_int32), ("tileBytes", C.c_int64)]
+
+
+_lib = None
+
+
+def lib_path() -> str:
+    return os.path.join(_HERE, "libcpuvox_gpu.so")
+
+
+def lib() -> C.CDLL:
+    """Load libcpuvox_gpu.so (built in-tree by cpuvox_amd/csrc/Makefile); fails loudly when missing."""
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing: the HIP extension is required (build with `make -C cpuvox_amd/csrc`); there is no CPU fallback")
+        L = C.CDLL(path)
+        L.cvx_version.restype = C.c_char_p
+        L.cvx_last_error.restype = C.c_char_p
+        L.cvx_last_error.argtypes = [C.c_void_p]
+        L.cvx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        L.cvx_destroy.argtypes = [C.c_void_p]
+        L.cvx_destroy.restype = None
+        L.cvx_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.cvx_world_upload.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.cvx_set_resolution.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.cvx_set_buffer_count.argtypes = [C.c_void_p, C.c_int]
+        L.cvx_draw_segments.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
+        L.cvx_draw_segments_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
+        L.cvx_set_shard.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.cvx_synchronize.argtypes = [C.c_void_p]
+        L.cvx_clear_raybuffer.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint32]
+        L.cvx_read_raybuffer.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.cvx_blit_segments.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.cvx_raybuffer_device_ptr.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        L.cvx_screen_device_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        L.cvx_last_draw_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.cvx_draw_time_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int]
+        L.cvx_enable_counters.argtypes = [C.c_void_p, C.c_int]
+        L.cvx_get_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
+        L.cvx_get_raybuffer_layout.argtypes = [C.c_void_p, C.c_int, C.POINTER(RaybufferLayout)]
+        L.cvx_bind_raybuffers.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
+        L.cvx_selftest_math.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+class CvxError(RuntimeError):
+    pass
+
+
+class Context:
+    """What RenderManager owns on the GPU side (RenderManager.cs:12-56): the
+    uploaded world LODs and the raybuffer pairs."""
+
+    def __init__(self, device: int = 0, buffer_count: int = 2):
+        self._h = C.c_void_p()
+        rc = lib().cvx_create(device, C.byref(self._h))
+        if rc != 0:
+            raise CvxError(f"cvx_create({device}) failed ({rc}): {lib().cvx_last_error(None).decode()}")
+        self.width = self.height = 0
+        if buffer_count != 2:
+            self._check(lib().cvx_set_buffer_count(self._h, buffer_count))
+        self.buffer_count = buffer_count
+
+    def _check(self, rc: int) -> None:
+        if rc != 0:
+            raise CvxError(f"cpuvox_gpu error {rc}: {lib().cvx_last_error(self._h).decode()}")
+
+    def close(self) -> None:
+        if self._h:
+            lib().cvx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- setup ------------------------------------------------------------
+    def set_stream(self, hip_stream: int | None) -> None:
+        self._check(lib().cvx_set_stream(self._h, C.c_void_p(hip_stream or 0)))
+
+    def upload_world(self, world_set: WorldSet) -> None:
+        """`fixed (World* worldPtr = worldLODs)` (RenderManager.cs:155): all LOD_LEVELS levels."""
+        for lod in range(world_set.lod_count):
+            i = world_set.info(lod)
+            self._check(lib().cvx_world_upload(self._h, lod, i.storage, i.byteLength, i.dimX, i.dimY, i.dimZ, i.columnCount))
+
+    def set_resolution(self, width: int, height: int) -> None:
+        """RenderManager.SetResolution (RenderManager.cs:94-109)."""
+        self._check(lib().cvx_set_resolution(self._h, width, height))
+        self.width, self.height = width, height
+
+    def set_shard(self, index: int, count: int) -> None:
+        self._check(lib().cvx_set_shard(self._h, index, count))
+
+    def enable_counters(self, enable: bool) -> None:
+        self._check(lib().cvx_enable_counters(self._h, int(enable)))
+
+    # -- the hot path -------------------------------------------------------
+    def draw_segments(self, frame: Frame, buffer_index: int = 0, flags: int = DRAW_SYNC) -> None:
+        """RenderManager.DrawSegments (RenderManager.cs:258-372)."""
+        vp = (C.c_float * 2)(*frame.vanishingPointScreenSpace)
+        self._check(lib().cvx_draw_segments(self._h, C.addressof(frame.segments), C.addressof(frame.camera), self.width, self.height,
+                                            C.addressof(vp), buffer_index, flags))
+
+    def draw_segments_batch(self, frames, first_buffer_index: int = 0, flags: int = DRAW_SYNC) -> None:
+        n = len(frames)
+        segs = (SegmentData * (4 * n))()
+        cams = (CameraData * n)()
+        vps = (C.c_float * (2 * n))()
+        for i, f in enumerate(frames):
+            for s in range(4):
+                segs[4 * i + s] = f.segments[s]
+            cams[i] = f.camera
+            vps[2 * i] = f.vanishingPointScreenSpace[0]
+            vps[2 * i + 1] = f.vanishingPointScreenSpace[1]
+        self._batch_keepalive = (segs, cams, vps)
+        self._check(lib().cvx_draw_segments_batch(self._h, n, C.addressof(segs), C.addressof(cams), self.width, self.height,
+                                                  C.addressof(vps), first_buffer_index, flags))
+
+    def pack_batch(self, frames):
+        """Marshal frames once; returns an opaque object for draw_packed (keeps bench loops free of Python overhead)."""
+        n = len(frames)
+        segs = (SegmentData * (4 * n))()
+        cams = (CameraData * n)()
+        vps = (C.c_float * (2 * n))()
+        for i, f in enumerate(frames):
+            for s in range(4):
+                segs[4 * i + s] = f.segments[s]
+            cams[i] = f.camera
+            vps[2 * i] = f.vanishingPointScreenSpace[0]
+            vps[2 * i + 1] = f.vanishingPointScreenSpace[1]
+        return (n, segs, cams, vps)
+
+    def draw_packed(self, packed, first_buffer_index: int = 0, flags: int = DRAW_SYNC) -> None:
+        n, segs, cams, vps = packed
+        self._check(lib().cvx_draw_segments_batch(self._h, n, C.addressof(segs), C.addressof(cams), self.width, self.height,
+                                                  C.addressof(vps), first_buffer_index, flags))
+
+    def synchronize(self) -> None:
+        self._check(lib().cvx_synchronize(self._h))
+
+    def last_draw_ms(self) -> float:
+        ms = C.c_float()
+        self._check(lib().cvx_last_draw_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def draw_time_stats(self, reset: bool = False):
+        """(total kernel ms, draws) since the last reset; HIP events on the context's stream."""
+        ms = C.c_double()
+        n = C.c_int()
+        self._check(lib().cvx_draw_time_stats(self._h, C.byref(ms), C.byref(n), int(reset)))
+        return ms.value, n.value
+
+    def counters(self) -> Counters:
+        out = Counters()
+        self._check(lib().cvx_get_counters(self._h, C.byref(out)))
+        return out
+
+    # -- raybuffers ---------------------------------------------------------
+    def clear_raybuffer(self, buffer_index: int, which: int, argb: int = 0) -> None:
+        """RenderManager.ClearRayBuffer (RenderManager.cs:58-92)."""
+        self._check(lib().cvx_clear_raybuffer(self._h, buffer_index, which, argb & 0xFFFFFFFF))
+
+    def clear_raybuffers(self, buffer_index: int = 0, argb: int = 0) -> None:
+        self.clear_raybuffer(buffer_index, RAYBUFFER_TOPDOWN, argb)
+        self.clear_raybuffer(buffer_index, RAYBUFFER_LEFTRIGHT, argb)
+
+    def read_raybuffer(self, buffer_index: int, which: int, first_ray: int = 0, ray_count: int | None = None) -> np.ndarray:
+        """Rows of a raybuffer in the reference's ray-major layout (RayBuffer.cs:121-128)."""
+        W, H = self.width, self.height
+        width = H if which == RAYBUFFER_TOPDOWN else W
+        cap = W + 2 * H if which == RAYBUFFER_TOPDOWN else 2 * W + H
+        if ray_count is None:
+            ray_count = cap - first_ray
+        out = np.empty((ray_count, width), dtype=np.uint32)
+        self._check(lib().cvx_read_raybuffer(self._h, buffer_index, which, first_ray, ray_count, out.ctypes.data))
+        return out
+
+    def blit_segments(self, buffer_index: int = 0, to_host: bool = True):
+        """RenderManager.BlitSegments + RayBufferBlit.shader (Phase 2) -> image[H, W] uint32, row 0 = bottom."""
+        if not to_host:
+            self._check(lib().cvx_blit_segments(self._h, buffer_index, None))
+            return None
+        out = np.empty((self.height, self.width), dtype=np.uint32)
+        self._check(lib().cvx_blit_segments(self._h, buffer_index, out.ctypes.data))
+        return out
+
+    def raybuffer_device_ptr(self, buffer_index: int, which: int):
+        p = C.c_void_p()
+        n = C.c_int64()
+        self._check(lib().cvx_raybuffer_device_ptr(self._h, buffer_index, which, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def bind_raybuffers(self, td_ptr: int, td_bytes: int, lr_ptr: int, lr_bytes: int) -> None:
+        """Render into caller-owned device memory (e.g. torch tensors used by a RCCL exchange)."""
+        self._check(lib().cvx_bind_raybuffers(self._h, C.c_void_p(td_ptr), td_bytes, C.c_void_p(lr_ptr), lr_bytes))
+
+    def raybuffer_layout(self, which: int) -> RaybufferLayout:
+        out = RaybufferLayout()
+        self._check(lib().cvx_get_raybuffer_layout(self._h, which, C.byref(out)))
+        return out
+
+    def selftest_math(self, op: int, a: np.ndarray, b: np.ndarray) -> np.ndarray:
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        b = np.ascontiguousarray(b, dtype=np.float32)
+        out = np.empty_like(a)
+        self._check(lib().cvx_selftest_math(self._h, op, a.size, a.ctypes.data, b.ctypes.data, out.ctypes.data))
+        return out

@@ -158,6 +158,12 @@ int cvx_read_raybuffer(cvx_context *ctx, int bufferIndex, int which, int firstRa
  */
 int cvx_blit_segments(cvx_context *ctx, int bufferIndex, void *dstHost);
 
+/* Use caller-owned device memory for the raybuffers (e.g. torch tensors that a RCCL collective
+ * operates on).  Sizes: bufferCount * tileCapacity * tileBytes per kind (cvx_get_raybuffer_layout),
+ * 256-byte aligned.  Buffer b of a kind starts at b * tileCapacity * tileBytes.  The context never
+ * frees bound memory; call after cvx_set_resolution (which allocates internal ones). */
+int cvx_bind_raybuffers(cvx_context *ctx, void *topDown, int64_t topDownBytes, void *leftRight, int64_t leftRightBytes);
+
 /* Device pointers for zero-copy consumers (RCCL gather, torch tensors). */
 int cvx_raybuffer_device_ptr(cvx_context *ctx, int bufferIndex, int which, void **ptr, int64_t *bytes);
 int cvx_screen_device_ptr(cvx_context *ctx, void **ptr, int64_t *bytes);
@@ -165,6 +171,9 @@ int cvx_screen_device_ptr(cvx_context *ctx, void **ptr, int64_t *bytes);
 /* Timing of the last draw call, measured with HIP events on the context's
  * stream (milliseconds; kernels only, no host setup). */
 int cvx_last_draw_ms(cvx_context *ctx, float *ms);
+/* Sum and count of the kernel times of all draws since the last reset (each draw is bracketed by its own
+ * HIP event pair on the context's stream; waits for pending draws). */
+int cvx_draw_time_stats(cvx_context *ctx, double *totalMs, int *draws, int reset);
 
 /* Enable in-kernel work counters (slower); read them after a SYNC draw. */
 int cvx_enable_counters(cvx_context *ctx, int enable);

@@ -525,7 +525,7 @@ static void execute_ray(const ray_continuation *rayContext, const draw_context *
 	                             &planeStartBottomProjected, &planeStartTopProjected, &planeRayDirectionProjected);
 
 	while (1) {
-		if (ray.intersectionDistances.x >= lodMax) { /* :237-243 */
+		if (ray.intersectionDistances.x >= lodMax && lod < ORC_LOD_LEVELS - 1) { /* :237-243 (+ the same guard) */
 			dda_next_lod(&ray, voxelScale);
 			lod++;
 			voxelScale *= 2;
@@ -920,7 +920,9 @@ static int trace_to_first_column_job(const ray_dda_context *inRays, const draw_c
 	if (startPos.x < 0 || startPos.y < 0 || startPos.x >= dimensions.x || startPos.y >= dimensions.y) {
 		f2 dimsf = { (float)dimensions.x, (float)dimensions.y };
 		if (dda_step_to_world_intersection(&cont->ddaRay, dimsf)) {
-			while (cont->ddaRay.intersectionDistances.x >= lodMax) {
+			/* "cont->lod < 5": memory-safety guard only (the reference would index LODDistances[6]);
+			 * a ray that far away is beyond far clip and becomes skybox either way. */
+			while (cont->ddaRay.intersectionDistances.x >= lodMax && cont->lod < ORC_LOD_LEVELS - 1) {
 				dda_next_lod(&cont->ddaRay, 1 << cont->lod);
 				cont->lod++;
 				world++;

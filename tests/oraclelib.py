@@ -89,15 +89,19 @@ def raybuffer_shapes(width: int, height: int):
     return (width + 2 * height, height), (2 * width + height, width)
 
 
-def draw_segments(world_set, frame, width: int, height: int, threads: int = 0, clear: int = 0, counters: bool = True):
+def draw_segments(world_set, frame, width: int, height: int, threads: int = 0, clear: int = 0, counters: bool = True, out=None):
     """Run the oracle's DrawSegments on a cpuvox_amd.host.Frame.
 
     Returns (topDown[rays, H] uint32, leftRight[rays, W] uint32, OrcCounters).
     Buffers are pre-cleared to `clear` (the reference leaves stale pixels).
     """
     (td_rays, td_w), (lr_rays, lr_w) = raybuffer_shapes(width, height)
-    td = np.full((td_rays, td_w), clear, dtype=np.uint32)
-    lr = np.full((lr_rays, lr_w), clear, dtype=np.uint32)
+    if out is not None:  # preallocated (and not cleared): timing runs
+        td, lr = out
+        assert td.shape == (td_rays, td_w) and lr.shape == (lr_rays, lr_w)
+    else:
+        td = np.full((td_rays, td_w), clear, dtype=np.uint32)
+        lr = np.full((lr_rays, lr_w), clear, dtype=np.uint32)
     worlds = orc_worlds(world_set)
     cnt = OrcCounters()
     vp = (C.c_float * 2)(*frame.vanishingPointScreenSpace)
