@@ -3,6 +3,7 @@
 // See include/cpuvox_gpu.h for the contract of every entry point.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -77,6 +78,8 @@ struct cvx_context {
 	size_t devTilesCap = 0;
 	std::vector<DevFrame> hostFrames;
 	std::vector<DevTile> hostTiles;
+	std::vector<float> hostTileCost; // estimated DDA steps of the tile's middle ray (launch order: longest first)
+	int maskWordsNeeded = 1;         // LDS mask words per lane the current launch needs
 
 	int shardIndex = 0, shardCount = 1;
 	bool countersEnabled = false;
@@ -158,6 +161,35 @@ int EnsureScratch(cvx_context *ctx, size_t frames, size_t tiles)
 	return CVX_OK;
 }
 
+// Launch-order heuristic only (never affects results): DDA column visits the tile's middle ray would make
+// if nothing occluded it = path length inside the world's XZ box (capped by far clip) * (|dx| + |dz|).
+float EstimateTileCost(const cvx_context *ctx, const DevFrame &F, const DevSegment &S, int tileInSeg)
+{
+	float t = ((float)(tileInSeg * CVX_WAVE + CVX_WAVE / 2)) / (float)(S.rayCount > 0 ? S.rayCount : 1);
+	if (t > 1.f) { t = 1.f; }
+	float dx = S.rayMinX + t * (S.rayMaxX - S.rayMinX);
+	float dz = S.rayMinZ + t * (S.rayMaxZ - S.rayMinZ);
+	float len = std::sqrt(dx * dx + dz * dz);
+	if (!(len > 0.f)) { return 0.f; }
+	dx /= len;
+	dz /= len;
+	float t0 = 0.f, t1 = F.farClip;
+	const float lo[2] = { 0.f, 0.f }, hi[2] = { (float)ctx->hostWorld.dimX, (float)ctx->hostWorld.dimZ };
+	const float o[2] = { F.posX, F.posZ }, d[2] = { dx, dz };
+	for (int a = 0; a < 2; a++) {
+		if (std::fabs(d[a]) < 1e-12f) {
+			if (o[a] < lo[a] || o[a] > hi[a]) { return 0.f; }
+			continue;
+		}
+		float ta = (lo[a] - o[a]) / d[a], tb = (hi[a] - o[a]) / d[a];
+		if (ta > tb) { float tmp = ta; ta = tb; tb = tmp; }
+		if (ta > t0) { t0 = ta; }
+		if (tb < t1) { t1 = tb; }
+	}
+	if (t1 <= t0) { return 0.f; }
+	return (t1 - t0) * (std::fabs(dx) + std::fabs(dz));
+}
+
 // Fills SegmentContext[4] the way DrawSegments does (RenderManager.cs:281-318)
 // and appends this frame's tiles.
 int BuildFrame(cvx_context *ctx, const cvx_segment_data segments[4], const cvx_camera_data *camera, int W, int H, const float vp[2],
@@ -225,11 +257,14 @@ int BuildFrame(cvx_context *ctx, const cvx_segment_data segments[4], const cvx_c
 		if (S.tileBase + segTiles > capacity) {
 			return Fail(ctx, CVX_ERR_CAPACITY, "segment %d: %d rays exceed the raybuffer capacity (RenderManager.cs:35-36)", s, rayCount);
 		}
+		const int maskWords = (S.omax >> 5) - (S.omin >> 5) + 1;
 		for (int t = 0; t < segTiles; t++, tileIdInFrame++) {
 			if (tileIdInFrame % ctx->shardCount != ctx->shardIndex) {
 				continue;
 			}
 			tiles.push_back(DevTile{ frameIndex, s, t, 0 });
+			ctx->hostTileCost.push_back(EstimateTileCost(ctx, F, S, t));
+			if (maskWords > ctx->maskWordsNeeded) { ctx->maskWordsNeeded = maskWords; }
 		}
 	}
 	// reference capacity check: TopDown holds W+2H rays, LeftRight 2W+H
@@ -295,7 +330,7 @@ int SyncWorld(cvx_context *ctx)
 	return CVX_OK;
 }
 
-int Launch(cvx_context *ctx, int frameCount, int W, int H, int flags)
+int Launch(cvx_context *ctx, int frameCount, int flags)
 {
 	size_t nTiles = ctx->hostTiles.size();
 	int rc = EnsureScratch(ctx, (size_t)frameCount, nTiles);
@@ -312,33 +347,16 @@ int Launch(cvx_context *ctx, int frameCount, int W, int H, int flags)
 	if (rc != CVX_OK) { return rc; }
 	CVX_HIP(ctx, hipEventRecord(evStart, ctx->stream));
 	if (nTiles) {
-		// All frames of one call share the iteration direction only if their
-		// cameras agree; split the launch per direction (RenderJob.Execute :174-178).
-		size_t begin = 0;
-		const int maxLen = W > H ? W : H;
-		const size_t ldsBytes = (size_t)((maxLen + 31) / 32) * CVX_WAVE * sizeof(uint32_t);
-		while (begin < nTiles) {
-			const int inverse = ctx->hostFrames[(size_t)ctx->hostTiles[begin].frame].inverse;
-			size_t end = begin;
-			while (end < nTiles && ctx->hostFrames[(size_t)ctx->hostTiles[end].frame].inverse == inverse) { end++; }
-			dim3 grid((unsigned)(end - begin)), block(CVX_WAVE);
-			const DevTile *tiles = ctx->devTiles + begin;
-			if (ctx->countersEnabled) {
-				if (inverse) {
-					hipLaunchKernelGGL((cvxk::render_kernel<-1, true>), grid, block, ldsBytes, ctx->stream, ctx->devFrames, tiles, ctx->devWorld, ctx->devCounters);
-				} else {
-					hipLaunchKernelGGL((cvxk::render_kernel<1, true>), grid, block, ldsBytes, ctx->stream, ctx->devFrames, tiles, ctx->devWorld, ctx->devCounters);
-				}
-			} else {
-				if (inverse) {
-					hipLaunchKernelGGL((cvxk::render_kernel<-1, false>), grid, block, ldsBytes, ctx->stream, ctx->devFrames, tiles, ctx->devWorld, ctx->devCounters);
-				} else {
-					hipLaunchKernelGGL((cvxk::render_kernel<1, false>), grid, block, ldsBytes, ctx->stream, ctx->devFrames, tiles, ctx->devWorld, ctx->devCounters);
-				}
-			}
-			CVX_HIP(ctx, hipGetLastError());
-			begin = end;
+		// One launch for the whole batch: the iteration direction (RenderJob.Execute :174-178) is a
+		// wave-uniform runtime switch inside the kernel, so tails of different frames overlap.
+		const size_t ldsBytes = (size_t)ctx->maskWordsNeeded * CVX_WAVE * sizeof(uint32_t);
+		dim3 grid((unsigned)nTiles), block(CVX_WAVE);
+		if (ctx->countersEnabled) {
+			hipLaunchKernelGGL((cvxk::render_kernel<true>), grid, block, ldsBytes, ctx->stream, ctx->devFrames, ctx->devTiles, ctx->devWorld, ctx->devCounters);
+		} else {
+			hipLaunchKernelGGL((cvxk::render_kernel<false>), grid, block, ldsBytes, ctx->stream, ctx->devFrames, ctx->devTiles, ctx->devWorld, ctx->devCounters);
 		}
+		CVX_HIP(ctx, hipGetLastError());
 	}
 	CVX_HIP(ctx, hipEventRecord(evStop, ctx->stream));
 	if (!(flags & CVX_DRAW_ASYNC)) {
@@ -599,24 +617,26 @@ int cvx_draw_segments_batch(cvx_context *ctx, int frameCount, const cvx_segment_
 	if (rc != CVX_OK) { return rc; }
 	ctx->hostFrames.assign((size_t)frameCount, DevFrame());
 	ctx->hostTiles.clear();
+	ctx->hostTileCost.clear();
+	ctx->maskWordsNeeded = 1;
 	for (int f = 0; f < frameCount; f++) {
 		int b = (firstBufferIndex + f) % ctx->bufferCount;
 		rc = BuildFrame(ctx, segments + (size_t)f * 4, cameras + f, screenWidth, screenHeight, vanishingPoints + (size_t)f * 2, b, f,
 		                ctx->hostFrames[(size_t)f], ctx->hostTiles, ctx->last[(size_t)b]);
 		if (rc != CVX_OK) { return rc; }
 	}
-	// group tiles by iteration direction so that each launch is one template instance
-	if (frameCount > 1) {
-		std::vector<DevTile> sorted;
-		sorted.reserve(ctx->hostTiles.size());
-		for (int pass = 0; pass < 2; pass++) {
-			for (const DevTile &t : ctx->hostTiles) {
-				if (ctx->hostFrames[(size_t)t.frame].inverse == pass) { sorted.push_back(t); }
-			}
-		}
+	// longest tiles first: the hardware dispatches workgroups in blockIdx order, so the tail of the launch is
+	// made of short tiles (LPT scheduling)
+	if (ctx->hostTiles.size() > 1) {
+		std::vector<uint32_t> order(ctx->hostTiles.size());
+		for (size_t i = 0; i < order.size(); i++) { order[i] = (uint32_t)i; }
+		const std::vector<float> &cost = ctx->hostTileCost;
+		std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+		std::vector<DevTile> sorted(ctx->hostTiles.size());
+		for (size_t i = 0; i < order.size(); i++) { sorted[i] = ctx->hostTiles[order[i]]; }
 		ctx->hostTiles.swap(sorted);
 	}
-	return Launch(ctx, frameCount, screenWidth, screenHeight, flags);
+	return Launch(ctx, frameCount, flags);
 }
 
 int cvx_draw_segments(cvx_context *ctx, const cvx_segment_data segments[4], const cvx_camera_data *camera, int screenWidth, int screenHeight,

@@ -669,7 +669,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 // ---------------------------------------------------------------------------
 // render kernel: grid = tiles, block = 64 (one wave).  LDS: words*64 uint32.
 // ---------------------------------------------------------------------------
-template <int DIR, bool COUNT>
+template <bool COUNT>
 __global__ __launch_bounds__(CVX_WAVE) void render_kernel(const DevFrame *__restrict__ frames, const DevTile *__restrict__ tiles,
                                                           const DevWorld *__restrict__ world, DevCounters *__restrict__ counters)
 {
@@ -679,8 +679,12 @@ __global__ __launch_bounds__(CVX_WAVE) void render_kernel(const DevFrame *__rest
 	const DevFrame &F = frames[tile.frame];
 	const DevSegment &S = F.seg[tile.seg];
 
+	// The mask only covers the words that hold pixels [omin, omax]; `seen` is biased so that the
+	// absolute word index w of a pixel addresses seen[w * 64].
 	const int colLen = S.colLen;
-	const int words = (colLen + 31) >> 5;
+	const int omin = S.omin, omax = S.omax;
+	const int wordBase = omin >> 5;
+	const int words = (omax >> 5) - wordBase + 1;
 	for (int w = 0; w < words; w++) {
 		lds[w * CVX_WAVE + lane] = 0u; // stackalloc is zero-initialised, :208
 	}
@@ -690,7 +694,7 @@ __global__ __launch_bounds__(CVX_WAVE) void render_kernel(const DevFrame *__rest
 	const bool active = planeRayIndex < S.rayCount;
 	uint32_t *pool = tile.seg < 2 ? F.poolTD : F.poolLR;
 	uint32_t *out = pool + ((size_t)(S.tileBase + tile.tileInSeg) * (size_t)colLen) * CVX_WAVE + lane;
-	uint32_t *seen = lds + lane;
+	uint32_t *seen = lds + lane - wordBase * CVX_WAVE;
 
 	LaneCounters cnt;
 	if (COUNT) {
@@ -699,12 +703,16 @@ __global__ __launch_bounds__(CVX_WAVE) void render_kernel(const DevFrame *__rest
 	}
 
 	if (active) {
-		trace_ray<DIR, COUNT>(F, S, world, planeRayIndex, seen, out, cnt);
+		// RenderJob.Execute :174-178: the iteration direction is a per-frame (wave-uniform) constant
+		if (F.inverse) {
+			trace_ray<-1, COUNT>(F, S, world, planeRayIndex, seen, out, cnt);
+		} else {
+			trace_ray<1, COUNT>(F, S, world, planeRayIndex, seen, out, cnt);
+		}
 	}
 
 	// WriteSkybox / WriteSkyboxFull (:699-716) for the whole wave: every pixel
 	// of [omin, omax] not marked seen gets the skybox colour.
-	const int omin = S.omin, omax = S.omax;
 	unsigned int skyPixels = 0;
 	for (int w = omin >> 5; w <= (omax >> 5); w++) {
 		uint32_t todo = ~seen[w * CVX_WAVE] & range_mask(w, omin, omax);

@@ -1,0 +1,104 @@
+"""CPU, gloo, world_size 2: the multi-GPU path's sharding + tile exchange (cpuvox_amd/dist.py).
+
+Each rank holds only the tiles it "rendered" (tile t of every frame with t % N == rank; the pixel data comes
+from the oracle, re-laid-out into the device's tile-major format by the test) and after TileExchange.run()
+frame f must be complete, bit for bit, on rank f % N."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oraclelib as O
+import scenes
+from cpuvox_amd import dist as cdist
+
+W, H = 320, 200
+TIMES = (0.1, 0.5, 0.75, 0.9, 1.1)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _tile_major(frame, td, lr, tiles_td, tiles_lr):
+    """Oracle ray-major buffers -> the tile-major pools libcpuvox_gpu renders into (cvx_device.h)."""
+    pool_td = np.zeros((tiles_td, H * 64), dtype=np.uint32)
+    pool_lr = np.zeros((tiles_lr, W * 64), dtype=np.uint32)
+    rc = [max(0, s.RayCount) for s in frame.segments]
+    for s in range(4):
+        pool, buf, col = (pool_td, td, H) if s < 2 else (pool_lr, lr, W)
+        row0 = rc[s - 1] if s in (1, 3) else 0
+        base = (rc[s - 1] + 63) // 64 if s in (1, 3) else 0
+        for plane in range(rc[s]):
+            pool[base + plane // 64].reshape(col, 64)[:, plane % 64] = buf[row0 + plane]
+    return pool_td, pool_lr
+
+
+def _worker(rank, world_size, port, result_queue):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        ws = scenes.load_world("proc256")
+        frames = [scenes.benchmark_frame(ws, W, H, t, 6.0) for t in TIMES]
+        tiles_td, tiles_lr = cdist.tile_capacity(W, H)
+        G = len(frames)
+        pools = cdist.Pools(torch.zeros((G * tiles_td, H * 64), dtype=torch.int32), torch.zeros((G * tiles_lr, W * 64), dtype=torch.int32), tiles_td, tiles_lr)
+        full = []
+        for b, fr in enumerate(frames):
+            td, lr, _ = O.draw_segments(ws, fr, W, H, threads=2)
+            ptd, plr = _tile_major(fr, td, lr, tiles_td, tiles_lr)
+            full.append((ptd, plr))
+            rc = [s.RayCount for s in fr.segments]
+            for t, (kind, tile) in enumerate(cdist.frame_tiles(rc)):
+                if t % world_size == rank:  # what cvx_set_shard(rank, N) renders on this rank
+                    if kind == 0:
+                        pools.td[b * tiles_td + tile] = torch.from_numpy(ptd[tile].view(np.int32))
+                    else:
+                        pools.lr[b * tiles_lr + tile] = torch.from_numpy(plr[tile].view(np.int32))
+        ex = cdist.TileExchange(frames, W, H, rank, world_size, pools, torch.device("cpu"))
+        ex.run()
+        ok = True
+        for b in range(G):
+            if b % world_size != rank:
+                continue
+            got_td = pools.td[b * tiles_td:(b + 1) * tiles_td].numpy().view(np.uint32)
+            got_lr = pools.lr[b * tiles_lr:(b + 1) * tiles_lr].numpy().view(np.uint32)
+            ok = ok and bool((got_td == full[b][0]).all() and (got_lr == full[b][1]).all())
+        result_queue.put((rank, ok, ex.sent_rows, ex.recv_rows))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tile_exchange_world_size_2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    results.sort()
+    assert all(ok for _, ok, _, _ in results), results
+    # every tile sent by one rank is received by the other
+    assert results[0][2] == results[1][3] and results[1][2] == results[0][3] and results[0][2] > 0
+
+
+def test_frame_tiles_matches_the_library_numbering():
+    """frame_tiles() mirrors BuildFrame() in cvx_gpu.hip: segment-major, segment 1/3 tiles follow 0/2 in their pool."""
+    tiles = cdist.frame_tiles([130, 64, 0, 65])
+    assert tiles == [(0, 0), (0, 1), (0, 2), (0, 3), (1, 0), (1, 1)]
+    assert cdist.frame_tiles([0, 0, 0, 0]) == []
+    assert cdist.tile_capacity(1920, 1080) == ((1920 + 2160 + 63) // 64 + 2, (3840 + 1080 + 63) // 64 + 2)
