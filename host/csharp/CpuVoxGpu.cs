@@ -1,0 +1,124 @@
+// CpuVoxGpu.cs -- P/Invoke binding of libcpuvox_gpu.so (include/cpuvox_gpu.h) for the reference's C# host.
+// No Unity, no Burst.  NOT compiled in this repository's image (no dotnet/mono/csc there); kept dependency-free
+// (System.Runtime.InteropServices only) so that `dotnet build` on any machine with a .NET SDK picks it up.
+// Struct layouts are the reference's own blittable structs:
+//   SegmentData  <- RenderManager.SegmentData (Assets/Code/RenderManager.cs:503-510)
+//   CameraData   <- CameraData (Assets/Code/Utils/CameraData.cs:11-16)
+using System;
+using System.Runtime.InteropServices;
+
+namespace CpuVox.Gpu
+{
+	[StructLayout(LayoutKind.Sequential, Pack = 4)]
+	public unsafe struct SegmentData
+	{
+		public fixed float MinScreen[2];
+		public fixed float MaxScreen[2];
+		public fixed float CamLocalPlaneRayMin[2];
+		public fixed float CamLocalPlaneRayMax[2];
+		public int RayCount;
+	}
+
+	[StructLayout(LayoutKind.Sequential, Pack = 4)]
+	public unsafe struct CameraData
+	{
+		public fixed float WorldToScreenMatrix[16]; // column major: c0, c1, c2, c3 (Unity.Mathematics.float4x4)
+		public fixed float PositionXZ[2];
+		public float PositionY;
+		public byte InverseElementIterationDirection; // C# bool in the reference struct
+		fixed byte pad[3];
+		public float FarClip;
+		public fixed float LODDistances[6];
+	}
+
+	[StructLayout(LayoutKind.Sequential)]
+	public unsafe struct Counters
+	{
+		public long S, E, C, P, R;
+		public fixed long LodVisits[6];
+	}
+
+	public sealed class CvxException : Exception
+	{
+		public readonly int Code;
+		public CvxException(int code, string message) : base(message) { Code = code; }
+	}
+
+	/// <summary>Raw entry points, one per declaration of include/cpuvox_gpu.h.</summary>
+	public static unsafe class Native
+	{
+		const string Lib = "cpuvox_gpu"; // libcpuvox_gpu.so
+
+		[DllImport(Lib)] public static extern int cvx_create(int device, out IntPtr ctx);
+		[DllImport(Lib)] public static extern void cvx_destroy(IntPtr ctx);
+		[DllImport(Lib)] public static extern IntPtr cvx_last_error(IntPtr ctx);
+		[DllImport(Lib)] public static extern int cvx_set_stream(IntPtr ctx, IntPtr hipStream);
+		[DllImport(Lib)] public static extern int cvx_world_upload(IntPtr ctx, int lod, void* storage, long byteLength, int dimX, int dimY, int dimZ, int columnCount);
+		[DllImport(Lib)] public static extern int cvx_set_resolution(IntPtr ctx, int resolutionX, int resolutionY);
+		[DllImport(Lib)] public static extern int cvx_set_buffer_count(IntPtr ctx, int bufferCount);
+		[DllImport(Lib)] public static extern int cvx_draw_segments(IntPtr ctx, SegmentData* segments, CameraData* camera, int screenWidth, int screenHeight, float* vanishingPointScreenSpace, int bufferIndex, int flags);
+		[DllImport(Lib)] public static extern int cvx_draw_segments_batch(IntPtr ctx, int frameCount, SegmentData* segments, CameraData* cameras, int screenWidth, int screenHeight, float* vanishingPoints, int firstBufferIndex, int flags);
+		[DllImport(Lib)] public static extern int cvx_set_shard(IntPtr ctx, int shardIndex, int shardCount);
+		[DllImport(Lib)] public static extern int cvx_synchronize(IntPtr ctx);
+		[DllImport(Lib)] public static extern int cvx_clear_raybuffer(IntPtr ctx, int bufferIndex, int which, uint argb);
+		[DllImport(Lib)] public static extern int cvx_read_raybuffer(IntPtr ctx, int bufferIndex, int which, int firstRay, int rayCount, void* dst);
+		[DllImport(Lib)] public static extern int cvx_blit_segments(IntPtr ctx, int bufferIndex, void* dstHost);
+		[DllImport(Lib)] public static extern int cvx_bind_raybuffers(IntPtr ctx, void* topDown, long topDownBytes, void* leftRight, long leftRightBytes);
+		[DllImport(Lib)] public static extern int cvx_raybuffer_device_ptr(IntPtr ctx, int bufferIndex, int which, out IntPtr ptr, out long bytes);
+		[DllImport(Lib)] public static extern int cvx_screen_device_ptr(IntPtr ctx, out IntPtr ptr, out long bytes);
+		[DllImport(Lib)] public static extern int cvx_last_draw_ms(IntPtr ctx, out float ms);
+		[DllImport(Lib)] public static extern int cvx_draw_time_stats(IntPtr ctx, out double totalMs, out int draws, int reset);
+		[DllImport(Lib)] public static extern int cvx_enable_counters(IntPtr ctx, int enable);
+		[DllImport(Lib)] public static extern int cvx_get_counters(IntPtr ctx, out Counters counters);
+		[DllImport(Lib)] public static extern IntPtr cvx_version();
+	}
+
+	/// <summary>
+	/// Owns the device-side state RenderManager owns in the reference (RenderManager.cs:12-56): uploaded world LODs and
+	/// the raybuffer pairs.  DrawSegments has the reference's signature minus the Unity texture wrappers.
+	/// </summary>
+	public sealed unsafe class GpuRenderer : IDisposable
+	{
+		IntPtr ctx;
+
+		public GpuRenderer(int device = 0)
+		{
+			int rc = Native.cvx_create(device, out ctx);
+			if (rc != 0) { throw new CvxException(rc, Marshal.PtrToStringAnsi(Native.cvx_last_error(IntPtr.Zero))); }
+		}
+
+		void Check(int rc)
+		{
+			if (rc != 0) { throw new CvxException(rc, Marshal.PtrToStringAnsi(Native.cvx_last_error(ctx))); }
+		}
+
+		/// <summary>Replaces `fixed (World* worldPtr = worldLODs)` (RenderManager.cs:155): hand over each World's raw storage.</summary>
+		public void UploadWorld(int lod, void* storageStartPointer, long byteLength, int dimX, int dimY, int dimZ, int columnCount)
+		{
+			Check(Native.cvx_world_upload(ctx, lod, storageStartPointer, byteLength, dimX, dimY, dimZ, columnCount));
+		}
+
+		/// <summary>RenderManager.SetResolution (RenderManager.cs:94-109).</summary>
+		public void SetResolution(int resolutionX, int resolutionY) { Check(Native.cvx_set_resolution(ctx, resolutionX, resolutionY)); }
+
+		/// <summary>RenderManager.DrawSegments (RenderManager.cs:258-372); blocks like render.Complete().</summary>
+		public void DrawSegments(SegmentData* segments4, CameraData* camera, int screenWidth, int screenHeight, float vpX, float vpY, int bufferIndex)
+		{
+			float* vp = stackalloc float[2];
+			vp[0] = vpX;
+			vp[1] = vpY;
+			Check(Native.cvx_draw_segments(ctx, segments4, camera, screenWidth, screenHeight, vp, bufferIndex, 0));
+		}
+
+		/// <summary>RenderManager.BlitSegments + RayBufferBlit.shader: W*H ARGB32 pixels, row 0 = bottom.</summary>
+		public void BlitSegments(int bufferIndex, void* dstArgb32) { Check(Native.cvx_blit_segments(ctx, bufferIndex, dstArgb32)); }
+
+		/// <summary>Rows of a raybuffer in the reference's layout (RayBuffer.Native.GetRayColumn, RayBuffer.cs:121-128).</summary>
+		public void ReadRayBuffer(int bufferIndex, int which, int firstRay, int rayCount, void* dst) { Check(Native.cvx_read_raybuffer(ctx, bufferIndex, which, firstRay, rayCount, dst)); }
+
+		public void Dispose()
+		{
+			if (ctx != IntPtr.Zero) { Native.cvx_destroy(ctx); ctx = IntPtr.Zero; }
+		}
+	}
+}
