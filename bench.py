@@ -123,7 +123,6 @@ def main():
         pools = cdist.allocate_pools(G, lay_td, lay_lr, device)
         ctx.bind_raybuffers(pools.td.data_ptr(), pools.td.numel() * 4, pools.lr.data_ptr(), pools.lr.numel() * 4)
         exchange = [cdist.TileExchange(frames, W, H, rank, N, pools, device) for frames in steps_frames]
-        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     packed = [ctx.pack_batch(frames) for frames in steps_frames]
     rays_per_step = [sum(f.totalRays for f in frames) for frames in steps_frames]
 
@@ -141,7 +140,10 @@ def main():
     def run_step(s: int):
         ctx.draw_packed(packed[s], 0, gpu.DRAW_ASYNC)
         if exchange is not None:
+            # the render stream belongs to the context, the exchange runs on torch's stream: order them on the host
+            ctx.synchronize()
             exchange[s].run()
+            torch.cuda.synchronize()
 
     for s in range(args.warmup):
         run_step(s)

@@ -21,7 +21,12 @@
 #define CVX_SKYBOX_ARGB 0x191919FFu /* ColorARGB32(25,25,25): bytes FF 19 19 19 (DrawSegmentRayJob.cs:702) */
 
 struct DevWorldLevel {
-	const uint4 *headers;     // {elemOffset, runCount | worldMin << 16, worldMax, 0}
+	// 32-byte column records, one table per element iteration direction:
+	//   [0] = {elemOffset, runCount | worldMin << 16, worldMax, 0}
+	//   [1] = the first four pool entries in walk order: entries 1..4 after the start guard (top-down walk,
+	//         ITERATION_DIRECTION +1) or entries runCount..runCount-3 (bottom-up walk, -1)
+	const uint4 *columnsDown;
+	const uint4 *columnsUp;
 	const uint32_t *elements; // RLEElement {int16 ColorsIndex, int16 Length} / ColorARGB32
 	int32_t shift;            // lod
 	int32_t mulX;             // dimZ >> lod

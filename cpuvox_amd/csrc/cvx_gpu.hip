@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -51,7 +52,7 @@ struct cvx_context {
 	std::string error;
 
 	// world
-	void *levelHeaders[CVX_LOD_LEVELS] = {};
+	void *levelHeaders[CVX_LOD_LEVELS] = {};   // columnsDown then columnsUp, one allocation
 	void *levelElements[CVX_LOD_LEVELS] = {};
 	bool levelSet[CVX_LOD_LEVELS] = {};
 	DevWorld hostWorld{};
@@ -349,7 +350,11 @@ int Launch(cvx_context *ctx, int frameCount, int flags)
 	if (nTiles) {
 		// One launch for the whole batch: the iteration direction (RenderJob.Execute :174-178) is a
 		// wave-uniform runtime switch inside the kernel, so tails of different frames overlap.
+#ifdef CVX_PROFILE_SECTIONS
+		const size_t ldsBytes = (size_t)ctx->maskWordsNeeded * CVX_WAVE * sizeof(uint32_t) + 128;
+#else
 		const size_t ldsBytes = (size_t)ctx->maskWordsNeeded * CVX_WAVE * sizeof(uint32_t);
+#endif
 		dim3 grid((unsigned)nTiles), block(CVX_WAVE);
 		if (ctx->countersEnabled) {
 			hipLaunchKernelGGL((cvxk::render_kernel<true>), grid, block, ldsBytes, ctx->stream, ctx->devFrames, ctx->devTiles, ctx->devWorld, ctx->devCounters);
@@ -449,7 +454,10 @@ int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byt
 
 	// Widen headers to 16 bytes and validate every column so that the kernel's
 	// element walk is guaranteed to terminate inside the pool.
-	std::vector<uint4> headers((size_t)(usedColumns > 0 ? usedColumns : 1));
+	// two tables of 32-byte records (cvx_device.h): [2*i] header, [2*i+1] element queue; down then up
+	const size_t tableEntries = (size_t)(usedColumns > 0 ? usedColumns : 1) * 2;
+	std::vector<uint4> headers(tableEntries * 2, uint4{ 0u, 0u, 0u, 0u });
+	auto entry = [&](int64_t off) -> uint32_t { return (off >= 0 && off < elementCount) ? elements[off] : 0u; };
 	const int maxY = dimY >> lod;
 	for (int64_t i = 0; i < usedColumns; i++) {
 		const RefHeader &h = src[i];
@@ -481,8 +489,12 @@ int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byt
 			d.x = (uint32_t)h.storageOffset;
 			d.y = (uint32_t)h.runCount | ((uint32_t)h.worldMin << 16);
 			d.z = (uint32_t)h.worldMax;
+			headers[(size_t)i * 2 + 1] = uint4{ entry(off + 1), entry(off + 2), entry(off + 3), entry(off + 4) };
+			const int64_t last = off + h.runCount;
+			headers[tableEntries + (size_t)i * 2 + 1] = uint4{ entry(last), entry(last - 1), entry(last - 2), entry(last - 3) };
 		}
-		headers[(size_t)i] = d;
+		headers[(size_t)i * 2] = d;
+		headers[tableEntries + (size_t)i * 2] = d;
 	}
 
 	CVX_HIP(ctx, hipSetDevice(ctx->device));
@@ -491,14 +503,19 @@ int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byt
 	if (ctx->levelElements[lod]) { (void)hipFree(ctx->levelElements[lod]); ctx->levelElements[lod] = nullptr; }
 	ctx->levelSet[lod] = false;
 	CVX_HIP(ctx, hipMalloc(&ctx->levelHeaders[lod], headers.size() * sizeof(uint4)));
-	CVX_HIP(ctx, hipMalloc(&ctx->levelElements[lod], (size_t)(elementCount > 0 ? elementCount : 1) * 4));
+	// 4 entries of zero padding on both sides: the kernel fetches element windows of 4 entries that may start
+	// up to 2 entries before / end up to 3 entries after a column's own range (cvx_kernels.h, element queue)
+	const size_t kPoolPad = 4;
+	CVX_HIP(ctx, hipMalloc(&ctx->levelElements[lod], ((size_t)(elementCount > 0 ? elementCount : 0) + 2 * kPoolPad) * 4));
+	CVX_HIP(ctx, hipMemset(ctx->levelElements[lod], 0, ((size_t)(elementCount > 0 ? elementCount : 0) + 2 * kPoolPad) * 4));
 	CVX_HIP(ctx, hipMemcpy(ctx->levelHeaders[lod], headers.data(), headers.size() * sizeof(uint4), hipMemcpyHostToDevice));
 	if (elementCount > 0) {
-		CVX_HIP(ctx, hipMemcpy(ctx->levelElements[lod], elements, (size_t)elementCount * 4, hipMemcpyHostToDevice));
+		CVX_HIP(ctx, hipMemcpy(static_cast<uint32_t *>(ctx->levelElements[lod]) + kPoolPad, elements, (size_t)elementCount * 4, hipMemcpyHostToDevice));
 	}
 	DevWorldLevel &L = ctx->hostWorld.level[lod];
-	L.headers = static_cast<const uint4 *>(ctx->levelHeaders[lod]);
-	L.elements = static_cast<const uint32_t *>(ctx->levelElements[lod]);
+	L.columnsDown = static_cast<const uint4 *>(ctx->levelHeaders[lod]);
+	L.columnsUp = L.columnsDown + tableEntries;
+	L.elements = static_cast<const uint32_t *>(ctx->levelElements[lod]) + kPoolPad;
 	L.shift = lod;
 	L.mulX = dimZ >> lod;
 	if (lod == 0) {
@@ -811,6 +828,28 @@ int cvx_get_raybuffer_layout(cvx_context *ctx, int which, cvx_raybuffer_layout *
 	out->tileCapacity = which == 0 ? ctx->tilesTD : ctx->tilesLR;
 	out->tileBytes = (int64_t)out->width * CVX_WAVE * 4;
 	return CVX_OK;
+}
+
+int cvx_debug_section_cycles(cvx_context *ctx, uint64_t out[16], int reset)
+{
+	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
+	if (!out) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "out is NULL"); }
+#ifdef CVX_PROFILE_SECTIONS
+	CVX_HIP(ctx, hipSetDevice(ctx->device));
+	CVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	unsigned long long tmp[16];
+	CVX_HIP(ctx, hipMemcpyFromSymbol(tmp, HIP_SYMBOL(cvxk::g_sectionCycles), sizeof tmp));
+	for (int i = 0; i < 16; i++) { out[i] = tmp[i]; }
+	if (reset) {
+		std::memset(tmp, 0, sizeof tmp);
+		CVX_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(cvxk::g_sectionCycles), tmp, sizeof tmp));
+	}
+	return CVX_OK;
+#else
+	(void)reset;
+	for (int i = 0; i < 16; i++) { out[i] = 0; }
+	return Fail(ctx, CVX_ERR_NOT_READY, "library was not built with -DCVX_PROFILE_SECTIONS (diagnostic build)");
+#endif
 }
 
 int cvx_selftest_math(cvx_context *ctx, int op, int n, const float *a, const float *b, float *out)

@@ -266,6 +266,26 @@ __device__ __forceinline__ void reduce_pixel_horizon(const uint32_t *seen, int o
 	}
 }
 
+// ---- diagnostic build only (-DCVX_PROFILE_SECTIONS): wave-level cycle shares per code section ----
+#ifdef CVX_PROFILE_SECTIONS
+__device__ unsigned long long g_sectionCycles[16];
+#define CVX_SEC(n) prof_mark(profLds, n)
+__device__ __forceinline__ void prof_mark(uint32_t *p, int sec)
+{
+	// p[0..15] cycles per section, p[16] current section, p[17] last stamp (low 32 bits)
+	const unsigned int t = (unsigned int)__builtin_amdgcn_s_memtime();
+	const unsigned long long exec = __ballot(1);
+	if ((int)(threadIdx.x & 63) == __ffsll((long long)exec) - 1) {
+		const unsigned int cur = p[16];
+		p[cur] += t - p[17];
+		p[17] = t;
+		p[16] = (unsigned int)sec;
+	}
+}
+#else
+#define CVX_SEC(n) ((void)0)
+#endif
+
 struct LaneCounters {
 	unsigned int S, E, C, P;
 	unsigned int lod[6];
@@ -278,8 +298,9 @@ struct LaneCounters {
 // ---------------------------------------------------------------------------
 template <int DIR, bool COUNT>
 __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S, const DevWorld *__restrict__ world, int planeRayIndex,
-                                          uint32_t *seen /* &lds[lane] */, uint32_t *out /* tile + lane */, LaneCounters &cnt)
+                                          uint32_t *seen /* &lds[lane] */, uint32_t *out /* tile + lane */, LaneCounters &cnt, uint32_t *profLds)
 {
+	(void)profLds;
 	const int omin = S.omin, omax = S.omax;
 	const float farClip = F.farClip;
 	const float posY = F.posY;
@@ -348,63 +369,30 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 	// A DDA walk is monotone in x and z, so it leaves the world after at most
 	// dimX + dimZ column visits; the cap can never bind on valid input and only
 	// keeps a wave from spinning on non-finite camera data.
-	for (int guardSteps = dimX + dimZ + 16; guardSteps > 0; guardSteps--) {
-		if (ray.distLast >= lodMax && lod < 5) { // :237-243
-			dda_next_lod(ray, voxelScale);
-			lod++;
-			voxelScale *= 2;
-			L = world->level[lod];
-			lodMax = F.lod[lod];
-		}
+	int guardSteps = dimX + dimZ + 16;
 
-		// World.GetVoxelColumn, World.cs:130-142
-		if ((ray.px & maskX) != ray.px || (ray.pz & maskZ) != ray.pz) {
-			return; // out of world bounds -> WriteSkybox
-		}
-		const uint4 header = L.headers[(ray.px >> L.shift) * L.mulX + (ray.pz >> L.shift)];
+	// The column being processed ("cur") and the values of the DDA / LOD state that belong to it; `ray` itself
+	// already stands on the NEXT column, whose 32-byte record is in flight while this one is processed.
+	uint4 header, queue;              // record of the current column: header + first four elements in walk order
+	float curDistLast, curDistNext;   // ray.IntersectionDistances of the current column
+	int curScale;                     // voxelScale of the current column
+	const uint32_t *curElements;      // element pool of the current column's LOD
+	float worldBoundsMin, worldBoundsMax;
+
+	// Clip, element walk and pixel writes of ExecuteRay (:289-611) for the current column;
+	// false = the ray is finished (every such exit is WriteSkybox).
+	auto drawColumn = [&]() -> bool {
 		const int columnRuns = (int)(header.y & 0xFFFFu);
-		if (COUNT) {
-			cnt.S++;
-#pragma unroll
-			for (int k = 0; k < 6; k++) { cnt.lod[k] += (lod == k) ? 1u : 0u; }
-		}
-		if (columnRuns == 0) {
-			if (dda_step(ray, farClip)) {
-				return;
-			}
-			continue;
-		}
-		const float columnWorldMin = (float)(header.y >> 16);
-		const float columnWorldMax = (float)(header.z & 0xFFFFu);
-
-		float worldBoundsMin = 0.0f;
-		float worldBoundsMax = worldMaxY;
-
-		if (frustumDirMaxWorld != CVX_FLOAT_EPSILON) { // :261-281
-			float distTop = frustumDirMaxWorld > 0.0f ? ray.distNext : ray.distLast;
-			float distBot = frustumDirMinWorld < 0.0f ? ray.distNext : ray.distLast;
-			float newMax = posY + frustumDirMaxWorld * distTop;
-			float newMin = posY + frustumDirMinWorld * distBot;
-			if (newMin > worldBoundsMax || newMax < worldBoundsMin) {
-				return;
-			}
-			if (columnWorldMin > newMax || columnWorldMax < newMin) {
-				if (dda_step(ray, farClip)) {
-					return;
-				}
-				continue;
-			}
-			worldBoundsMin = newMin;
-			worldBoundsMax = newMax;
-		}
-
+		CVX_SEC(2);
+		const uint32_t *guardStart = curElements + header.x; // RLEColumn.ElementGuardStart, World.cs:175
+		uint32_t q0 = queue.x, q1 = queue.y, q2 = queue.z, q3 = queue.w;
 		// :289-293
-		const f3 camSpaceMinLast = f3_madd(planeStartBottom, planeDir, ray.distLast);
-		const f3 camSpaceMinNext = f3_madd(planeStartBottom, planeDir, ray.distNext);
-		const f3 camSpaceMaxLast = f3_madd(planeStartTop, planeDir, ray.distLast);
-		const f3 camSpaceMaxNext = f3_madd(planeStartTop, planeDir, ray.distNext);
+		const f3 camSpaceMinLast = f3_madd(planeStartBottom, planeDir, curDistLast);
+		const f3 camSpaceMinNext = f3_madd(planeStartBottom, planeDir, curDistNext);
+		const f3 camSpaceMaxLast = f3_madd(planeStartTop, planeDir, curDistLast);
+		const f3 camSpaceMaxNext = f3_madd(planeStartTop, planeDir, curDistNext);
 
-		if (ray.distLast > 2.0f && frustumDirMaxWorld == CVX_FLOAT_EPSILON) { // :295-422
+		if (curDistLast > 2.0f && frustumDirMaxWorld == CVX_FLOAT_EPSILON) { // :295-422
 			float clipLastMinLerp, clipLastMaxLerp, clipNextMinLerp, clipNextMaxLerp;
 			const bool clippedLast = clip_world_bounds(camSpaceMinLast, camSpaceMaxLast, frustumBoundsMin, frustumBoundsMax, clipLastMinLerp, clipLastMaxLerp);
 			const bool clippedNext = clip_world_bounds(camSpaceMinNext, camSpaceMaxNext, frustumBoundsMin, frustumBoundsMax, clipNextMinLerp, clipNextMaxLerp);
@@ -412,12 +400,12 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			float camSpaceClippedMin, camSpaceClippedMax;
 			if (clippedLast) {
 				if (clippedNext) {
-					return;
+					return false;
 				}
 				worldBoundsMin = m_lerp(0.0f, worldMaxY, clipNextMinLerp);
 				worldBoundsMax = m_lerp(0.0f, worldMaxY, clipNextMaxLerp);
-				frustumDirMaxWorld = (worldBoundsMax - posY) / ray.distNext;
-				frustumDirMinWorld = (worldBoundsMin - posY) / ray.distNext;
+				frustumDirMaxWorld = (worldBoundsMax - posY) / curDistNext;
+				frustumDirMinWorld = (worldBoundsMin - posY) / curDistNext;
 				f3 minClip = f3_lerp(camSpaceMinNext, camSpaceMaxNext, clipNextMinLerp);
 				f3 maxClip = f3_lerp(camSpaceMinNext, camSpaceMaxNext, clipNextMaxLerp);
 				camSpaceClippedMin = minClip.x / minClip.z;
@@ -430,8 +418,8 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 				worldBoundsMax = m_lerp(0.0f, worldMaxY, clipLastMaxLerp);
 				f3 minClip = f3_lerp(camSpaceMinLast, camSpaceMaxLast, clipLastMinLerp);
 				f3 maxClip = f3_lerp(camSpaceMinLast, camSpaceMaxLast, clipLastMaxLerp);
-				frustumDirMaxWorld = (worldBoundsMax - posY) / ray.distLast;
-				frustumDirMinWorld = (worldBoundsMin - posY) / ray.distLast;
+				frustumDirMaxWorld = (worldBoundsMax - posY) / curDistLast;
+				frustumDirMinWorld = (worldBoundsMin - posY) / curDistLast;
 				camSpaceClippedMin = minClip.x / minClip.z;
 				camSpaceClippedMax = maxClip.x / maxClip.z;
 				if (camSpaceClippedMax < camSpaceClippedMin) {
@@ -440,17 +428,17 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			} else {
 				if (clipLastMinLerp < clipNextMinLerp) {
 					worldBoundsMin = m_lerp(0.0f, worldMaxY, clipLastMinLerp);
-					frustumDirMinWorld = (worldBoundsMin - posY) / ray.distLast;
+					frustumDirMinWorld = (worldBoundsMin - posY) / curDistLast;
 				} else {
 					worldBoundsMin = m_lerp(0.0f, worldMaxY, clipNextMinLerp);
-					frustumDirMinWorld = (worldBoundsMin - posY) / ray.distNext;
+					frustumDirMinWorld = (worldBoundsMin - posY) / curDistNext;
 				}
 				if (clipLastMaxLerp > clipNextMaxLerp) {
 					worldBoundsMax = m_lerp(0.0f, worldMaxY, clipLastMaxLerp);
-					frustumDirMaxWorld = (worldBoundsMax - posY) / ray.distLast;
+					frustumDirMaxWorld = (worldBoundsMax - posY) / curDistLast;
 				} else {
 					worldBoundsMax = m_lerp(0.0f, worldMaxY, clipNextMaxLerp);
-					frustumDirMaxWorld = (worldBoundsMax - posY) / ray.distNext;
+					frustumDirMaxWorld = (worldBoundsMax - posY) / curDistNext;
 				}
 				f3 minClipA = f3_lerp(camSpaceMinLast, camSpaceMaxLast, clipLastMinLerp);
 				f3 maxClipA = f3_lerp(camSpaceMinLast, camSpaceMaxLast, clipLastMaxLerp);
@@ -473,7 +461,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			const int writableMaxPixel = f2i(ceilf(camSpaceClippedMax));
 
 			if (writableMaxPixel < nextFreePixelMin || writableMinPixel > nextFreePixelMax) {
-				return;
+				return false;
 			}
 			if (writableMinPixel > nextFreePixelMin) {
 				nextFreePixelMin = scan_up(seen, writableMinPixel, omax);
@@ -482,14 +470,19 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 				nextFreePixelMax = scan_down(seen, writableMaxPixel, omin);
 			}
 			if (nextFreePixelMin > nextFreePixelMax) {
-				return;
+				return false;
 			}
 		}
 
+		CVX_SEC(3);
 		// ---- element loop, :424-611
 		float elementBoundsMin, elementBoundsMax;
-		const uint32_t *guardStart = L.elements + header.x; // RLEColumn.ElementGuardStart, World.cs:175
 		const uint32_t *elementPointer;
+		// The first four elements in walk order travel with the column record (q0..q3), so typical columns
+		// (<= 3 runs + guard) never touch the element pool; longer ones continue with single loads (the walk is
+		// a chain of dependent 4-byte loads in the reference).  Entries of the queue beyond the guard are never
+		// consumed.
+		int queued = 4;
 		if (DIR > 0) {
 			elementBoundsMin = worldMaxY;
 			elementBoundsMax = worldMaxY;
@@ -502,8 +495,15 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		const uint32_t *worldColumnColors = guardStart + columnRuns + 2; // ColorPointer, World.cs:185
 
 		while (true) {
+			CVX_SEC(3);
 			elementPointer += DIR;
-			const uint32_t raw = *elementPointer;
+			uint32_t raw;
+			if (queued > 0) {
+				raw = q0; q0 = q1; q1 = q2; q2 = q3;
+				queued--;
+			} else {
+				raw = *elementPointer;
+			}
 			const int elementColorsIndex = (int)(short)(raw & 0xFFFFu);
 			const int elementLength = (int)(short)(raw >> 16);
 			if (COUNT) { cnt.E++; }
@@ -513,10 +513,10 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 
 			if (DIR > 0) {
 				elementBoundsMax = elementBoundsMin;
-				elementBoundsMin = elementBoundsMin - (float)(elementLength * voxelScale);
+				elementBoundsMin = elementBoundsMin - (float)(elementLength * curScale);
 			} else {
 				elementBoundsMin = elementBoundsMax;
-				elementBoundsMax = elementBoundsMin + (float)(elementLength * voxelScale);
+				elementBoundsMax = elementBoundsMin + (float)(elementLength * curScale);
 			}
 
 			if (elementColorsIndex < 0) {
@@ -535,6 +535,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			f3 camSpaceFrontTop = f3_lerp(camSpaceMinLast, camSpaceMaxLast, portionTop);
 
 			// side of the run, :484-542
+			CVX_SEC(4);
 			{
 				float uA = (float)elementLength;
 				float uB = 0.0f;
@@ -566,6 +567,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 					int rbMax = f2i(rintf(boundsY));
 					if (rbMax >= nextFreePixelMin && rbMin <= nextFreePixelMax) {
 						reduce_pixel_horizon(seen, omin, omax, rbMin, rbMax, nextFreePixelMin, nextFreePixelMax, frustumBoundsMin, frustumBoundsMax);
+						CVX_SEC(5);
 						for (int w = rbMin >> 5; w <= (rbMax >> 5); w++) { // pixel loop :519-533 over unseen bits
 							const uint32_t range = range_mask(w, rbMin, rbMax);
 							const uint32_t m = seen[w * CVX_WAVE];
@@ -587,13 +589,14 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 							}
 						}
 						if (nextFreePixelMin > nextFreePixelMax) {
-							return;
+							return false;
 						}
 					}
 				}
 			}
 
 			// top / bottom of the run, :544-610
+			CVX_SEC(6);
 			f3 secA, secB;
 			uint32_t secondaryColor;
 			if (portionTop < cameraPosYNormalized) {
@@ -638,6 +641,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 				}
 				if (rbMax >= nextFreePixelMin && rbMin <= nextFreePixelMax) {
 					reduce_pixel_horizon(seen, omin, omax, rbMin, rbMax, nextFreePixelMin, nextFreePixelMax, frustumBoundsMin, frustumBoundsMax);
+					CVX_SEC(7);
 					for (int w = rbMin >> 5; w <= (rbMax >> 5); w++) { // :595-603
 						const uint32_t range = range_mask(w, rbMin, rbMax);
 						const uint32_t m = seen[w * CVX_WAVE];
@@ -654,15 +658,105 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 						}
 					}
 					if (nextFreePixelMin > nextFreePixelMax) {
-						return;
+						return false;
 					}
 				}
 			}
 		}
 
-		if (dda_step(ray, farClip)) {
+		return true;
+	};
+
+	const uint4 *table = DIR > 0 ? L.columnsDown : L.columnsUp;
+
+	// column 0: LOD check (:237-243), bounds test and fetch (World.GetVoxelColumn, World.cs:130-142)
+	if (ray.distLast >= lodMax && lod < 5) {
+		dda_next_lod(ray, voxelScale);
+		lod++;
+		voxelScale *= 2;
+		L = world->level[lod];
+		table = DIR > 0 ? L.columnsDown : L.columnsUp;
+		lodMax = F.lod[lod];
+	}
+	if ((ray.px & maskX) != ray.px || (ray.pz & maskZ) != ray.pz) {
+		return; // out of world bounds -> WriteSkybox
+	}
+	{
+		const uint4 *rec = table + 2 * (size_t)((ray.px >> L.shift) * L.mulX + (ray.pz >> L.shift));
+		header = rec[0];
+		queue = rec[1];
+	}
+
+	while (true) {
+		CVX_SEC(1);
+		if (--guardSteps <= 0) {
 			return;
 		}
+		// ---- look ahead: move the DDA to the next column (Step :613 / :252 / :273, then the LOD check of the
+		// next iteration :237-243) and start fetching its record; nothing below touches `ray` again.
+		curDistLast = ray.distLast;
+		curDistNext = ray.distNext;
+		curScale = voxelScale;
+		curElements = L.elements;
+		const int curLod = lod;
+		const bool lastColumn = dda_step(ray, farClip); // true: far clip reached after this column
+		bool nextOutside = false;
+		uint4 nextHeader = { 0u, 0u, 0u, 0u }, nextQueue = { 0u, 0u, 0u, 0u };
+		if (!lastColumn) {
+			if (ray.distLast >= lodMax && lod < 5) {
+				dda_next_lod(ray, voxelScale);
+				lod++;
+				voxelScale *= 2;
+				L = world->level[lod];
+				table = DIR > 0 ? L.columnsDown : L.columnsUp;
+				lodMax = F.lod[lod];
+			}
+			nextOutside = (ray.px & maskX) != ray.px || (ray.pz & maskZ) != ray.pz;
+			if (!nextOutside) {
+				const uint4 *rec = table + 2 * (size_t)((ray.px >> L.shift) * L.mulX + (ray.pz >> L.shift));
+				nextHeader = rec[0];
+				nextQueue = rec[1];
+			}
+		}
+
+		// ---- the current column, exactly as the reference processes it
+		if (COUNT) {
+			cnt.S++;
+#pragma unroll
+			for (int k = 0; k < 6; k++) { cnt.lod[k] += (curLod == k) ? 1u : 0u; }
+		}
+		if ((header.y & 0xFFFFu) != 0u) { // not an empty column (:251-256)
+			bool draw = true;
+			worldBoundsMin = 0.0f;
+			worldBoundsMax = worldMaxY;
+			if (frustumDirMaxWorld != CVX_FLOAT_EPSILON) { // :261-281
+				const float columnWorldMin = (float)(header.y >> 16);
+				const float columnWorldMax = (float)(header.z & 0xFFFFu);
+				float distTop = frustumDirMaxWorld > 0.0f ? curDistNext : curDistLast;
+				float distBot = frustumDirMinWorld < 0.0f ? curDistNext : curDistLast;
+				float newMax = posY + frustumDirMaxWorld * distTop;
+				float newMin = posY + frustumDirMinWorld * distBot;
+				if (newMin > worldBoundsMax || newMax < worldBoundsMin) {
+					return; // frustum left the world entirely
+				}
+				if (columnWorldMin > newMax || columnWorldMax < newMin) {
+					draw = false; // this column does not overlap the writable world bounds
+				} else {
+					worldBoundsMin = newMin;
+					worldBoundsMax = newMax;
+				}
+			}
+			if (draw && !drawColumn()) {
+				return;
+			}
+		}
+
+		// ---- next column
+		if (lastColumn || nextOutside) {
+			return; // far clip reached / left the world: WriteSkybox
+		}
+		header = nextHeader;
+		queue = nextQueue;
 	}
 }
 
@@ -695,6 +789,14 @@ __global__ __launch_bounds__(CVX_WAVE) void render_kernel(const DevFrame *__rest
 	uint32_t *pool = tile.seg < 2 ? F.poolTD : F.poolLR;
 	uint32_t *out = pool + ((size_t)(S.tileBase + tile.tileInSeg) * (size_t)colLen) * CVX_WAVE + lane;
 	uint32_t *seen = lds + lane - wordBase * CVX_WAVE;
+#ifdef CVX_PROFILE_SECTIONS
+	uint32_t *profLds = lds + words * CVX_WAVE; // 18 words behind the mask (the diagnostic build launches with +128 bytes)
+	if (lane < 18) { profLds[lane] = 0u; }
+	if (lane == 0) { profLds[17] = (unsigned int)__builtin_amdgcn_s_memtime(); }
+	__builtin_amdgcn_s_barrier();
+#else
+	uint32_t *profLds = nullptr;
+#endif
 
 	LaneCounters cnt;
 	if (COUNT) {
@@ -705,14 +807,15 @@ __global__ __launch_bounds__(CVX_WAVE) void render_kernel(const DevFrame *__rest
 	if (active) {
 		// RenderJob.Execute :174-178: the iteration direction is a per-frame (wave-uniform) constant
 		if (F.inverse) {
-			trace_ray<-1, COUNT>(F, S, world, planeRayIndex, seen, out, cnt);
+			trace_ray<-1, COUNT>(F, S, world, planeRayIndex, seen, out, cnt, profLds);
 		} else {
-			trace_ray<1, COUNT>(F, S, world, planeRayIndex, seen, out, cnt);
+			trace_ray<1, COUNT>(F, S, world, planeRayIndex, seen, out, cnt, profLds);
 		}
 	}
 
 	// WriteSkybox / WriteSkyboxFull (:699-716) for the whole wave: every pixel
 	// of [omin, omax] not marked seen gets the skybox colour.
+	CVX_SEC(8);
 	unsigned int skyPixels = 0;
 	for (int w = omin >> 5; w <= (omax >> 5); w++) {
 		uint32_t todo = ~seen[w * CVX_WAVE] & range_mask(w, omin, omax);
@@ -727,6 +830,10 @@ __global__ __launch_bounds__(CVX_WAVE) void render_kernel(const DevFrame *__rest
 		if (COUNT) { skyPixels += (unsigned int)__popc(todo); }
 	}
 
+#ifdef CVX_PROFILE_SECTIONS
+	CVX_SEC(0);
+	if (lane < 16) { atomicAdd(&g_sectionCycles[lane], (unsigned long long)profLds[lane]); }
+#endif
 	if (COUNT) {
 		cnt.P += skyPixels;
 		atomicAdd(&counters->S, (unsigned long long)cnt.S);

@@ -28,7 +28,7 @@ EXPORTS = [
     "cvx_set_buffer_count", "cvx_draw_segments", "cvx_draw_segments_batch", "cvx_set_shard", "cvx_synchronize",
     "cvx_clear_raybuffer", "cvx_read_raybuffer", "cvx_blit_segments", "cvx_raybuffer_device_ptr",
     "cvx_screen_device_ptr", "cvx_last_draw_ms", "cvx_enable_counters", "cvx_get_counters",
-    "cvx_get_raybuffer_layout", "cvx_selftest_math", "cvx_version", "cvx_bind_raybuffers", "cvx_draw_time_stats",
+    "cvx_get_raybuffer_layout", "cvx_selftest_math", "cvx_version", "cvx_bind_raybuffers", "cvx_draw_time_stats", "cvx_debug_section_cycles",
 ]
 
 
@@ -53,7 +53,8 @@ _lib = None
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, "libcpuvox_gpu.so")
+    # CVX_GPU_LIB selects another build of the same ABI (e.g. the diagnostic libcpuvox_gpu_prof.so); never a CPU path
+    return os.environ.get("CVX_GPU_LIB") or os.path.join(_HERE, "libcpuvox_gpu.so")
 
 
 def lib() -> C.CDLL:
@@ -89,6 +90,7 @@ def lib() -> C.CDLL:
         L.cvx_get_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
         L.cvx_get_raybuffer_layout.argtypes = [C.c_void_p, C.c_int, C.POINTER(RaybufferLayout)]
         L.cvx_bind_raybuffers.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
+        L.cvx_debug_section_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
         L.cvx_selftest_math.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
@@ -252,6 +254,12 @@ class Context:
         out = RaybufferLayout()
         self._check(lib().cvx_get_raybuffer_layout(self._h, which, C.byref(out)))
         return out
+
+    def debug_section_cycles(self, reset: bool = False):
+        """Diagnostic build only: wave cycles per render-kernel section (include/cpuvox_gpu.h)."""
+        out = (C.c_uint64 * 16)()
+        self._check(lib().cvx_debug_section_cycles(self._h, out, int(reset)))
+        return list(out)
 
     def selftest_math(self, op: int, a: np.ndarray, b: np.ndarray) -> np.ndarray:
         a = np.ascontiguousarray(a, dtype=np.float32)

@@ -189,6 +189,12 @@ typedef struct cvx_raybuffer_layout {
 } cvx_raybuffer_layout;
 int cvx_get_raybuffer_layout(cvx_context *ctx, int which, cvx_raybuffer_layout *out);
 
+/* Diagnostic build only (make gpu-prof, -DCVX_PROFILE_SECTIONS): wave cycles spent per code section of the
+ * render kernel (s_memtime stamps), accumulated over all launches.  Sections: 0 prologue/epilogue, 1 phase A
+ * (DDA step + header + cull), 2 frustum clip, 3 element walk, 4 side-face setup, 5 side-face pixels,
+ * 6 top/bottom setup, 7 top/bottom pixels, 8 skybox pass.  The regular build returns CVX_ERR_NOT_READY. */
+int cvx_debug_section_cycles(cvx_context *ctx, uint64_t out[16], int reset);
+
 /* Arithmetic self-test hook used by tests: evaluates op on n float pairs on
  * the device.  op: 0 a/b, 1 sqrt(a), 2 1/sqrt(a), 3 a*b+c style lerp a+b*(b-a),
  * 4 floor, 5 ceil, 6 round-half-even, 7 (int)a with the x86 rule. */
