@@ -27,6 +27,9 @@ struct DevWorldLevel {
 	//         ITERATION_DIRECTION +1) or entries runCount..runCount-3 (bottom-up walk, -1)
 	const uint4 *columnsDown;
 	const uint4 *columnsUp;
+	// entries 5..8 in walk order per column (read only for columns with more than 3 runs)
+	const uint4 *extDown;
+	const uint4 *extUp;
 	const uint32_t *elements; // RLEElement {int16 ColorsIndex, int16 Length} / ColorARGB32
 	int32_t shift;            // lod
 	int32_t mulX;             // dimZ >> lod

@@ -80,7 +80,16 @@ struct cvx_context {
 	std::vector<DevFrame> hostFrames;
 	std::vector<DevTile> hostTiles;
 	std::vector<float> hostTileCost; // estimated DDA steps of the tile's middle ray (launch order: longest first)
-	int maskWordsNeeded = 1;         // LDS mask words per lane the current launch needs
+	std::vector<int> hostTileWords;  // LDS mask words per lane the tile needs
+	// The kernel is latency bound: throughput scales with resident waves, and LDS (the per-lane seen mask) is
+	// what limits them.  LDS size is fixed per launch, so tiles are bucketed by mask size and every bucket is
+	// launched with exactly the LDS it needs, on its own stream, concurrently.
+	static constexpr int kBuckets = 4;
+	hipStream_t bucketStream[kBuckets] = {};
+	hipEvent_t bucketReady = nullptr;
+	hipEvent_t bucketDone[kBuckets] = {};
+	size_t bucketBegin[kBuckets + 1] = {};
+	int bucketWords[kBuckets] = {};
 
 	int shardIndex = 0, shardCount = 1;
 	bool countersEnabled = false;
@@ -265,7 +274,7 @@ int BuildFrame(cvx_context *ctx, const cvx_segment_data segments[4], const cvx_c
 			}
 			tiles.push_back(DevTile{ frameIndex, s, t, 0 });
 			ctx->hostTileCost.push_back(EstimateTileCost(ctx, F, S, t));
-			if (maskWords > ctx->maskWordsNeeded) { ctx->maskWordsNeeded = maskWords; }
+			ctx->hostTileWords.push_back(maskWords);
 		}
 	}
 	// reference capacity check: TopDown holds W+2H rays, LeftRight 2W+H
@@ -348,20 +357,27 @@ int Launch(cvx_context *ctx, int frameCount, int flags)
 	if (rc != CVX_OK) { return rc; }
 	CVX_HIP(ctx, hipEventRecord(evStart, ctx->stream));
 	if (nTiles) {
-		// One launch for the whole batch: the iteration direction (RenderJob.Execute :174-178) is a
-		// wave-uniform runtime switch inside the kernel, so tails of different frames overlap.
-#ifdef CVX_PROFILE_SECTIONS
-		const size_t ldsBytes = (size_t)ctx->maskWordsNeeded * CVX_WAVE * sizeof(uint32_t) + 128;
-#else
-		const size_t ldsBytes = (size_t)ctx->maskWordsNeeded * CVX_WAVE * sizeof(uint32_t);
-#endif
-		dim3 grid((unsigned)nTiles), block(CVX_WAVE);
-		if (ctx->countersEnabled) {
-			hipLaunchKernelGGL((cvxk::render_kernel<true>), grid, block, ldsBytes, ctx->stream, ctx->devFrames, ctx->devTiles, ctx->devWorld, ctx->devCounters);
-		} else {
-			hipLaunchKernelGGL((cvxk::render_kernel<false>), grid, block, ldsBytes, ctx->stream, ctx->devFrames, ctx->devTiles, ctx->devWorld, ctx->devCounters);
+		// The iteration direction (RenderJob.Execute :174-178) is a wave-uniform runtime switch inside the kernel,
+		// so one launch per LDS bucket covers all frames of the batch; the buckets run concurrently.
+		static const size_t ldsPad = getenv("CVX_LDS_PAD") ? (size_t)atoi(getenv("CVX_LDS_PAD")) : 0; // occupancy experiments only
+		CVX_HIP(ctx, hipEventRecord(ctx->bucketReady, ctx->stream));
+		for (int b = 0; b < cvx_context::kBuckets; b++) {
+			const size_t begin = ctx->bucketBegin[b], end = ctx->bucketBegin[b + 1];
+			if (end <= begin) { continue; }
+			hipStream_t st = ctx->bucketStream[b];
+			CVX_HIP(ctx, hipStreamWaitEvent(st, ctx->bucketReady, 0));
+			const size_t ldsBytes = (size_t)ctx->bucketWords[b] * CVX_WAVE * sizeof(uint32_t) + ldsPad;
+			dim3 grid((unsigned)(end - begin)), block(CVX_WAVE);
+			const DevTile *tiles = ctx->devTiles + begin;
+			if (ctx->countersEnabled) {
+				hipLaunchKernelGGL((cvxk::render_kernel<true>), grid, block, ldsBytes, st, ctx->devFrames, tiles, ctx->devWorld, ctx->devCounters);
+			} else {
+				hipLaunchKernelGGL((cvxk::render_kernel<false>), grid, block, ldsBytes, st, ctx->devFrames, tiles, ctx->devWorld, ctx->devCounters);
+			}
+			CVX_HIP(ctx, hipGetLastError());
+			CVX_HIP(ctx, hipEventRecord(ctx->bucketDone[b], st));
+			CVX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->bucketDone[b], 0));
 		}
-		CVX_HIP(ctx, hipGetLastError());
 	}
 	CVX_HIP(ctx, hipEventRecord(evStop, ctx->stream));
 	if (!(flags & CVX_DRAW_ASYNC)) {
@@ -400,6 +416,11 @@ int cvx_create(int device, cvx_context **out)
 	if ((e = hipStreamCreateWithFlags(&ctx->ownStream, hipStreamNonBlocking)) != hipSuccess) { return bail(e, "hipStreamCreate"); }
 	ctx->stream = ctx->ownStream;
 	if ((e = hipMalloc((void **)&ctx->devCounters, sizeof(DevCounters))) != hipSuccess) { return bail(e, "hipMalloc"); }
+	if ((e = hipEventCreateWithFlags(&ctx->bucketReady, hipEventDisableTiming)) != hipSuccess) { return bail(e, "hipEventCreate"); }
+	for (int b = 0; b < cvx_context::kBuckets; b++) {
+		if ((e = hipStreamCreateWithFlags(&ctx->bucketStream[b], hipStreamNonBlocking)) != hipSuccess) { return bail(e, "hipStreamCreate"); }
+		if ((e = hipEventCreateWithFlags(&ctx->bucketDone[b], hipEventDisableTiming)) != hipSuccess) { return bail(e, "hipEventCreate"); }
+	}
 	*out = ctx;
 	return CVX_OK;
 }
@@ -420,6 +441,11 @@ void cvx_destroy(cvx_context *ctx)
 	if (ctx->devCounters) { (void)hipFree(ctx->devCounters); }
 	if (ctx->staging) { (void)hipFree(ctx->staging); }
 	for (hipEvent_t e : ctx->evPairs) { (void)hipEventDestroy(e); }
+	if (ctx->bucketReady) { (void)hipEventDestroy(ctx->bucketReady); }
+	for (int b = 0; b < cvx_context::kBuckets; b++) {
+		if (ctx->bucketDone[b]) { (void)hipEventDestroy(ctx->bucketDone[b]); }
+		if (ctx->bucketStream[b]) { (void)hipStreamDestroy(ctx->bucketStream[b]); }
+	}
 	if (ctx->ownStream) { (void)hipStreamDestroy(ctx->ownStream); }
 	delete ctx;
 }
@@ -454,9 +480,11 @@ int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byt
 
 	// Widen headers to 16 bytes and validate every column so that the kernel's
 	// element walk is guaranteed to terminate inside the pool.
-	// two tables of 32-byte records (cvx_device.h): [2*i] header, [2*i+1] element queue; down then up
-	const size_t tableEntries = (size_t)(usedColumns > 0 ? usedColumns : 1) * 2;
-	std::vector<uint4> headers(tableEntries * 2, uint4{ 0u, 0u, 0u, 0u });
+	// two tables of 32-byte records (cvx_device.h): [2*i] header, [2*i+1] element queue; down then up; then the
+	// two 16-byte-per-column extension tables (entries 5..8)
+	const size_t columnsAlloc = (size_t)(usedColumns > 0 ? usedColumns : 1);
+	const size_t tableEntries = columnsAlloc * 2;
+	std::vector<uint4> headers(tableEntries * 2 + columnsAlloc * 2, uint4{ 0u, 0u, 0u, 0u });
 	auto entry = [&](int64_t off) -> uint32_t { return (off >= 0 && off < elementCount) ? elements[off] : 0u; };
 	const int maxY = dimY >> lod;
 	for (int64_t i = 0; i < usedColumns; i++) {
@@ -492,6 +520,8 @@ int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byt
 			headers[(size_t)i * 2 + 1] = uint4{ entry(off + 1), entry(off + 2), entry(off + 3), entry(off + 4) };
 			const int64_t last = off + h.runCount;
 			headers[tableEntries + (size_t)i * 2 + 1] = uint4{ entry(last), entry(last - 1), entry(last - 2), entry(last - 3) };
+			headers[tableEntries * 2 + (size_t)i] = uint4{ entry(off + 5), entry(off + 6), entry(off + 7), entry(off + 8) };
+			headers[tableEntries * 2 + columnsAlloc + (size_t)i] = uint4{ entry(last - 4), entry(last - 5), entry(last - 6), entry(last - 7) };
 		}
 		headers[(size_t)i * 2] = d;
 		headers[tableEntries + (size_t)i * 2] = d;
@@ -515,6 +545,8 @@ int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byt
 	DevWorldLevel &L = ctx->hostWorld.level[lod];
 	L.columnsDown = static_cast<const uint4 *>(ctx->levelHeaders[lod]);
 	L.columnsUp = L.columnsDown + tableEntries;
+	L.extDown = L.columnsDown + tableEntries * 2;
+	L.extUp = L.extDown + columnsAlloc;
 	L.elements = static_cast<const uint32_t *>(ctx->levelElements[lod]) + kPoolPad;
 	L.shift = lod;
 	L.mulX = dimZ >> lod;
@@ -635,23 +667,74 @@ int cvx_draw_segments_batch(cvx_context *ctx, int frameCount, const cvx_segment_
 	ctx->hostFrames.assign((size_t)frameCount, DevFrame());
 	ctx->hostTiles.clear();
 	ctx->hostTileCost.clear();
-	ctx->maskWordsNeeded = 1;
+	ctx->hostTileWords.clear();
 	for (int f = 0; f < frameCount; f++) {
 		int b = (firstBufferIndex + f) % ctx->bufferCount;
 		rc = BuildFrame(ctx, segments + (size_t)f * 4, cameras + f, screenWidth, screenHeight, vanishingPoints + (size_t)f * 2, b, f,
 		                ctx->hostFrames[(size_t)f], ctx->hostTiles, ctx->last[(size_t)b]);
 		if (rc != CVX_OK) { return rc; }
 	}
-	// longest tiles first: the hardware dispatches workgroups in blockIdx order, so the tail of the launch is
-	// made of short tiles (LPT scheduling)
-	if (ctx->hostTiles.size() > 1) {
-		std::vector<uint32_t> order(ctx->hostTiles.size());
-		for (size_t i = 0; i < order.size(); i++) { order[i] = (uint32_t)i; }
+	// Bucket tiles by LDS need (<= 8, 17, 34, more mask words per lane); inside a bucket longest tiles first: the
+	// hardware dispatches workgroups in blockIdx order, so the tail of a launch is made of short tiles (LPT).
+	{
+		// Measured on MI355X: the runtime serialises launches that share a hardware queue and resident waves
+		// beyond ~10 per CU no longer add throughput, so by default everything goes into ONE bucket (one launch,
+		// one tail).  CVX_LDS_BUCKETS=1 restores the 4-way split for experiments.
+		static const bool split = getenv("CVX_LDS_BUCKETS") && atoi(getenv("CVX_LDS_BUCKETS")) != 0;
+		static const int kLimitSplit[cvx_context::kBuckets] = { 8, 17, 34, 1 << 30 };
+		static const int kLimitOne[cvx_context::kBuckets] = { 1 << 30, 1 << 30, 1 << 30, 1 << 30 };
+		const int *kLimit = split ? kLimitSplit : kLimitOne;
+		const size_t n = ctx->hostTiles.size();
+		std::vector<uint32_t> order(n);
+		std::vector<uint8_t> bucket(n);
+		for (size_t i = 0; i < n; i++) {
+			order[i] = (uint32_t)i;
+			int b = 0;
+			while (ctx->hostTileWords[i] > kLimit[b]) { b++; }
+			bucket[i] = (uint8_t)b;
+		}
 		const std::vector<float> &cost = ctx->hostTileCost;
-		std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
-		std::vector<DevTile> sorted(ctx->hostTiles.size());
-		for (size_t i = 0; i < order.size(); i++) { sorted[i] = ctx->hostTiles[order[i]]; }
+		std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+			return bucket[a] != bucket[b] ? bucket[a] < bucket[b] : cost[a] > cost[b];
+		});
+		std::vector<DevTile> sorted(n);
+		for (int b = 0; b <= cvx_context::kBuckets; b++) { ctx->bucketBegin[b] = n; }
+		for (int b = 0; b < cvx_context::kBuckets; b++) { ctx->bucketWords[b] = 1; }
+		for (size_t i = 0; i < n; i++) {
+			const uint32_t src = order[i];
+			sorted[i] = ctx->hostTiles[src];
+			const int b = bucket[src];
+			if (i < ctx->bucketBegin[b]) { ctx->bucketBegin[b] = i; }
+			if (ctx->hostTileWords[src] > ctx->bucketWords[b]) { ctx->bucketWords[b] = ctx->hostTileWords[src]; }
+		}
+		for (int b = cvx_context::kBuckets - 1; b >= 0; b--) { // empty buckets start where the next one starts
+			if (ctx->bucketBegin[b] > ctx->bucketBegin[b + 1]) { ctx->bucketBegin[b] = ctx->bucketBegin[b + 1]; }
+		}
 		ctx->hostTiles.swap(sorted);
+	}
+	// XCD affinity: workgroup b is observed to run on XCD b % 8 (MI355X_MICROARCH.md, dispatch round-robin; speed
+	// only, never correctness).  Keep all tiles of a frame on one XCD so that the columns near the camera, which
+	// many of the frame's rays visit, are served by that XCD's L2.  Slot i*8+k holds the i-th tile (LPT order) of
+	// the frames with f % 8 == k; when a list runs out the remaining slots are filled from the others.
+	static const bool xcdAffinity = !(getenv("CVX_XCD_AFFINITY") && atoi(getenv("CVX_XCD_AFFINITY")) == 0);
+	if (xcdAffinity && frameCount >= 8 && ctx->bucketBegin[1] == ctx->hostTiles.size()) {
+		const size_t n = ctx->hostTiles.size();
+		std::vector<DevTile> lists[8];
+		for (const DevTile &t : ctx->hostTiles) { lists[t.frame & 7].push_back(t); }
+		std::vector<DevTile> out;
+		out.reserve(n);
+		size_t cursor[8] = {};
+		std::vector<DevTile> leftovers;
+		size_t minLen = n;
+		for (int k = 0; k < 8; k++) { if (lists[k].size() < minLen) { minLen = lists[k].size(); } }
+		for (size_t i = 0; i < minLen; i++) {
+			for (int k = 0; k < 8; k++) { out.push_back(lists[k][cursor[k]++]); }
+		}
+		for (int k = 0; k < 8; k++) {
+			while (cursor[k] < lists[k].size()) { leftovers.push_back(lists[k][cursor[k]++]); }
+		}
+		out.insert(out.end(), leftovers.begin(), leftovers.end());
+		ctx->hostTiles.swap(out);
 	}
 	return Launch(ctx, frameCount, flags);
 }
@@ -830,16 +913,25 @@ int cvx_get_raybuffer_layout(cvx_context *ctx, int which, cvx_raybuffer_layout *
 	return CVX_OK;
 }
 
-int cvx_debug_section_cycles(cvx_context *ctx, uint64_t out[16], int reset)
+int cvx_debug_occupancy(cvx_context *ctx, int64_t ldsBytes, int *blocksPerCU)
+{
+	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
+	if (!blocksPerCU) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "blocksPerCU is NULL"); }
+	CVX_HIP(ctx, hipSetDevice(ctx->device));
+	CVX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, cvxk::render_kernel<false>, CVX_WAVE, (size_t)ldsBytes));
+	return CVX_OK;
+}
+
+int cvx_debug_section_cycles(cvx_context *ctx, uint64_t out[32], int reset)
 {
 	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
 	if (!out) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "out is NULL"); }
 #ifdef CVX_PROFILE_SECTIONS
 	CVX_HIP(ctx, hipSetDevice(ctx->device));
 	CVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	unsigned long long tmp[16];
+	unsigned long long tmp[32];
 	CVX_HIP(ctx, hipMemcpyFromSymbol(tmp, HIP_SYMBOL(cvxk::g_sectionCycles), sizeof tmp));
-	for (int i = 0; i < 16; i++) { out[i] = tmp[i]; }
+	for (int i = 0; i < 32; i++) { out[i] = tmp[i]; }
 	if (reset) {
 		std::memset(tmp, 0, sizeof tmp);
 		CVX_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(cvxk::g_sectionCycles), tmp, sizeof tmp));
@@ -847,7 +939,7 @@ int cvx_debug_section_cycles(cvx_context *ctx, uint64_t out[16], int reset)
 	return CVX_OK;
 #else
 	(void)reset;
-	for (int i = 0; i < 16; i++) { out[i] = 0; }
+	for (int i = 0; i < 32; i++) { out[i] = 0; }
 	return Fail(ctx, CVX_ERR_NOT_READY, "library was not built with -DCVX_PROFILE_SECTIONS (diagnostic build)");
 #endif
 }

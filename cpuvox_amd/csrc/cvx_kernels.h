@@ -266,24 +266,24 @@ __device__ __forceinline__ void reduce_pixel_horizon(const uint32_t *seen, int o
 	}
 }
 
-// ---- diagnostic build only (-DCVX_PROFILE_SECTIONS): wave-level cycle shares per code section ----
+// ---- diagnostic build only (-DCVX_PROFILE_SECTIONS): per-lane cycle accounting of code sections ----
+// CVX_BEGIN() stamps, CVX_END(n) adds the cycles since the last stamp to section n -- in every lane that is active
+// at both points.  Sections never nest.  Cost: one s_memtime + two VALU ops per mark (the build is only read for
+// shares).  Reported per section: max over the lanes of a wave (~ wave time in the section), summed over waves, and
+// the lane sum (lane-cycles; / (64 * wave time) = lane utilisation).
 #ifdef CVX_PROFILE_SECTIONS
-__device__ unsigned long long g_sectionCycles[16];
-#define CVX_SEC(n) prof_mark(profLds, n)
-__device__ __forceinline__ void prof_mark(uint32_t *p, int sec)
-{
-	// p[0..15] cycles per section, p[16] current section, p[17] last stamp (low 32 bits)
-	const unsigned int t = (unsigned int)__builtin_amdgcn_s_memtime();
-	const unsigned long long exec = __ballot(1);
-	if ((int)(threadIdx.x & 63) == __ffsll((long long)exec) - 1) {
-		const unsigned int cur = p[16];
-		p[cur] += t - p[17];
-		p[17] = t;
-		p[16] = (unsigned int)sec;
-	}
-}
+#define CVX_NSEC 9
+__device__ unsigned long long g_sectionCycles[32]; // [n] wave cycles, [16+n] lane cycles / 64
+struct ProfLane {
+	unsigned int last;
+	unsigned int acc[CVX_NSEC];
+};
+#define CVX_BEGIN() (prof.last = (unsigned int)__builtin_amdgcn_s_memtime())
+#define CVX_END(n) do { const unsigned int t_ = (unsigned int)__builtin_amdgcn_s_memtime(); prof.acc[n] += t_ - prof.last; prof.last = t_; } while (0)
 #else
-#define CVX_SEC(n) ((void)0)
+struct ProfLane {};
+#define CVX_BEGIN() ((void)0)
+#define CVX_END(n) ((void)0)
 #endif
 
 struct LaneCounters {
@@ -298,9 +298,9 @@ struct LaneCounters {
 // ---------------------------------------------------------------------------
 template <int DIR, bool COUNT>
 __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S, const DevWorld *__restrict__ world, int planeRayIndex,
-                                          uint32_t *seen /* &lds[lane] */, uint32_t *out /* tile + lane */, LaneCounters &cnt, uint32_t *profLds)
+                                          uint32_t *seen /* &lds[lane] */, uint32_t *out /* tile + lane */, LaneCounters &cnt, ProfLane &prof)
 {
-	(void)profLds;
+	(void)prof;
 	const int omin = S.omin, omax = S.omax;
 	const float farClip = F.farClip;
 	const float posY = F.posY;
@@ -377,15 +377,21 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 	float curDistLast, curDistNext;   // ray.IntersectionDistances of the current column
 	int curScale;                     // voxelScale of the current column
 	const uint32_t *curElements;      // element pool of the current column's LOD
+	const uint4 *curExt;              // entries 5..8 (walk order) of the current column, fetched only when it has > 3 runs
 	float worldBoundsMin, worldBoundsMax;
 
 	// Clip, element walk and pixel writes of ExecuteRay (:289-611) for the current column;
 	// false = the ray is finished (every such exit is WriteSkybox).
 	auto drawColumn = [&]() -> bool {
 		const int columnRuns = (int)(header.y & 0xFFFFu);
-		CVX_SEC(2);
+		CVX_BEGIN();
 		const uint32_t *guardStart = curElements + header.x; // RLEColumn.ElementGuardStart, World.cs:175
 		uint32_t q0 = queue.x, q1 = queue.y, q2 = queue.z, q3 = queue.w;
+		uint4 ext = { 0u, 0u, 0u, 0u };
+		if (columnRuns > 3) {
+			ext = *curExt; // issued now, needed after four elements: the latency hides behind the clip / first run
+		}
+		bool extPending = true;
 		// :289-293
 		const f3 camSpaceMinLast = f3_madd(planeStartBottom, planeDir, curDistLast);
 		const f3 camSpaceMinNext = f3_madd(planeStartBottom, planeDir, curDistNext);
@@ -474,7 +480,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			}
 		}
 
-		CVX_SEC(3);
+		CVX_END(2);
 		// ---- element loop, :424-611
 		float elementBoundsMin, elementBoundsMax;
 		const uint32_t *elementPointer;
@@ -494,39 +500,59 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		}
 		const uint32_t *worldColumnColors = guardStart + columnRuns + 2; // ColorPointer, World.cs:185
 
+		// Element loop :441-611, realigned for SIMT: every lane first walks its own elements (cheap: decode,
+		// bounds bookkeeping, air / world-bounds culls :445-475) up to its next run that has to be projected;
+		// the expensive projection + pixel code below then runs once for all lanes that found one, instead of
+		// once per element index with whatever lanes happen to hold a solid run at that index.  The sequence of
+		// elements each lane consumes is unchanged.
 		while (true) {
-			CVX_SEC(3);
-			elementPointer += DIR;
-			uint32_t raw;
-			if (queued > 0) {
-				raw = q0; q0 = q1; q1 = q2; q2 = q3;
-				queued--;
-			} else {
-				raw = *elementPointer;
-			}
-			const int elementColorsIndex = (int)(short)(raw & 0xFFFFu);
-			const int elementLength = (int)(short)(raw >> 16);
-			if (COUNT) { cnt.E++; }
-			if (elementLength == 0) {
+			int elementColorsIndex = 0, elementLength = 0;
+			bool found = false;
+			CVX_BEGIN();
+			while (true) {
+				elementPointer += DIR;
+				uint32_t raw;
+				if (queued == 0 && extPending) {
+					q0 = ext.x; q1 = ext.y; q2 = ext.z; q3 = ext.w;
+					queued = 4;
+					extPending = false;
+				}
+				if (queued > 0) {
+					raw = q0; q0 = q1; q1 = q2; q2 = q3;
+					queued--;
+				} else {
+					raw = *elementPointer;
+				}
+				elementColorsIndex = (int)(short)(raw & 0xFFFFu);
+				elementLength = (int)(short)(raw >> 16);
+				if (COUNT) { cnt.E++; }
+				if (elementLength == 0) {
+					break; // guard: end of the column
+				}
+
+				if (DIR > 0) {
+					elementBoundsMax = elementBoundsMin;
+					elementBoundsMin = elementBoundsMin - (float)(elementLength * curScale);
+				} else {
+					elementBoundsMin = elementBoundsMax;
+					elementBoundsMax = elementBoundsMin + (float)(elementLength * curScale);
+				}
+
+				if (elementColorsIndex < 0) {
+					continue; // air
+				}
+				if (elementBoundsMin > worldBoundsMax) {
+					if (DIR < 0) { break; } else { continue; }
+				}
+				if (elementBoundsMax < worldBoundsMin) {
+					if (DIR > 0) { break; } else { continue; }
+				}
+				found = true;
 				break;
 			}
-
-			if (DIR > 0) {
-				elementBoundsMax = elementBoundsMin;
-				elementBoundsMin = elementBoundsMin - (float)(elementLength * curScale);
-			} else {
-				elementBoundsMin = elementBoundsMax;
-				elementBoundsMax = elementBoundsMin + (float)(elementLength * curScale);
-			}
-
-			if (elementColorsIndex < 0) {
-				continue;
-			}
-			if (elementBoundsMin > worldBoundsMax) {
-				if (DIR < 0) { break; } else { continue; }
-			}
-			if (elementBoundsMax < worldBoundsMin) {
-				if (DIR > 0) { break; } else { continue; }
+			CVX_END(3);
+			if (!found) {
+				break;
 			}
 
 			const float portionBottom = (elementBoundsMin - 0.0f) / (worldMaxY - 0.0f); // unlerp(0, worldMaxY, x)
@@ -535,7 +561,6 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			f3 camSpaceFrontTop = f3_lerp(camSpaceMinLast, camSpaceMaxLast, portionTop);
 
 			// side of the run, :484-542
-			CVX_SEC(4);
 			{
 				float uA = (float)elementLength;
 				float uB = 0.0f;
@@ -567,7 +592,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 					int rbMax = f2i(rintf(boundsY));
 					if (rbMax >= nextFreePixelMin && rbMin <= nextFreePixelMax) {
 						reduce_pixel_horizon(seen, omin, omax, rbMin, rbMax, nextFreePixelMin, nextFreePixelMax, frustumBoundsMin, frustumBoundsMax);
-						CVX_SEC(5);
+						CVX_END(4);
 						for (int w = rbMin >> 5; w <= (rbMax >> 5); w++) { // pixel loop :519-533 over unseen bits
 							const uint32_t range = range_mask(w, rbMin, rbMax);
 							const uint32_t m = seen[w * CVX_WAVE];
@@ -588,6 +613,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 								} while (todo != 0u);
 							}
 						}
+						CVX_END(5);
 						if (nextFreePixelMin > nextFreePixelMax) {
 							return false;
 						}
@@ -596,7 +622,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			}
 
 			// top / bottom of the run, :544-610
-			CVX_SEC(6);
+			CVX_END(4); // (remainder of) the side block
 			f3 secA, secB;
 			uint32_t secondaryColor;
 			if (portionTop < cameraPosYNormalized) {
@@ -641,7 +667,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 				}
 				if (rbMax >= nextFreePixelMin && rbMin <= nextFreePixelMax) {
 					reduce_pixel_horizon(seen, omin, omax, rbMin, rbMax, nextFreePixelMin, nextFreePixelMax, frustumBoundsMin, frustumBoundsMax);
-					CVX_SEC(7);
+					CVX_END(6);
 					for (int w = rbMin >> 5; w <= (rbMax >> 5); w++) { // :595-603
 						const uint32_t range = range_mask(w, rbMin, rbMax);
 						const uint32_t m = seen[w * CVX_WAVE];
@@ -657,6 +683,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 							} while (todo != 0u);
 						}
 					}
+					CVX_END(7);
 					if (nextFreePixelMin > nextFreePixelMax) {
 						return false;
 					}
@@ -668,6 +695,8 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 	};
 
 	const uint4 *table = DIR > 0 ? L.columnsDown : L.columnsUp;
+	const uint4 *extTable = DIR > 0 ? L.extDown : L.extUp;
+	const uint4 *nextExt;
 
 	// column 0: LOD check (:237-243), bounds test and fetch (World.GetVoxelColumn, World.cs:130-142)
 	if (ray.distLast >= lodMax && lod < 5) {
@@ -676,19 +705,22 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		voxelScale *= 2;
 		L = world->level[lod];
 		table = DIR > 0 ? L.columnsDown : L.columnsUp;
+		extTable = DIR > 0 ? L.extDown : L.extUp;
 		lodMax = F.lod[lod];
 	}
 	if ((ray.px & maskX) != ray.px || (ray.pz & maskZ) != ray.pz) {
 		return; // out of world bounds -> WriteSkybox
 	}
 	{
-		const uint4 *rec = table + 2 * (size_t)((ray.px >> L.shift) * L.mulX + (ray.pz >> L.shift));
+		const size_t column = (size_t)((ray.px >> L.shift) * L.mulX + (ray.pz >> L.shift));
+		const uint4 *rec = table + 2 * column;
 		header = rec[0];
 		queue = rec[1];
+		nextExt = extTable + column;
 	}
 
 	while (true) {
-		CVX_SEC(1);
+		CVX_BEGIN();
 		if (--guardSteps <= 0) {
 			return;
 		}
@@ -698,6 +730,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		curDistNext = ray.distNext;
 		curScale = voxelScale;
 		curElements = L.elements;
+		curExt = nextExt;
 		const int curLod = lod;
 		const bool lastColumn = dda_step(ray, farClip); // true: far clip reached after this column
 		bool nextOutside = false;
@@ -709,13 +742,16 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 				voxelScale *= 2;
 				L = world->level[lod];
 				table = DIR > 0 ? L.columnsDown : L.columnsUp;
+				extTable = DIR > 0 ? L.extDown : L.extUp;
 				lodMax = F.lod[lod];
 			}
 			nextOutside = (ray.px & maskX) != ray.px || (ray.pz & maskZ) != ray.pz;
 			if (!nextOutside) {
-				const uint4 *rec = table + 2 * (size_t)((ray.px >> L.shift) * L.mulX + (ray.pz >> L.shift));
+				const size_t column = (size_t)((ray.px >> L.shift) * L.mulX + (ray.pz >> L.shift));
+				const uint4 *rec = table + 2 * column;
 				nextHeader = rec[0];
 				nextQueue = rec[1];
+				nextExt = extTable + column;
 			}
 		}
 
@@ -746,9 +782,11 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 					worldBoundsMax = newMax;
 				}
 			}
+			CVX_END(1);
 			if (draw && !drawColumn()) {
 				return;
 			}
+			CVX_BEGIN();
 		}
 
 		// ---- next column
@@ -757,6 +795,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		}
 		header = nextHeader;
 		queue = nextQueue;
+		CVX_END(1);
 	}
 }
 
@@ -789,13 +828,10 @@ __global__ __launch_bounds__(CVX_WAVE) void render_kernel(const DevFrame *__rest
 	uint32_t *pool = tile.seg < 2 ? F.poolTD : F.poolLR;
 	uint32_t *out = pool + ((size_t)(S.tileBase + tile.tileInSeg) * (size_t)colLen) * CVX_WAVE + lane;
 	uint32_t *seen = lds + lane - wordBase * CVX_WAVE;
+	ProfLane prof;
 #ifdef CVX_PROFILE_SECTIONS
-	uint32_t *profLds = lds + words * CVX_WAVE; // 18 words behind the mask (the diagnostic build launches with +128 bytes)
-	if (lane < 18) { profLds[lane] = 0u; }
-	if (lane == 0) { profLds[17] = (unsigned int)__builtin_amdgcn_s_memtime(); }
-	__builtin_amdgcn_s_barrier();
-#else
-	uint32_t *profLds = nullptr;
+	for (int i = 0; i < CVX_NSEC; i++) { prof.acc[i] = 0u; }
+	CVX_BEGIN();
 #endif
 
 	LaneCounters cnt;
@@ -807,15 +843,15 @@ __global__ __launch_bounds__(CVX_WAVE) void render_kernel(const DevFrame *__rest
 	if (active) {
 		// RenderJob.Execute :174-178: the iteration direction is a per-frame (wave-uniform) constant
 		if (F.inverse) {
-			trace_ray<-1, COUNT>(F, S, world, planeRayIndex, seen, out, cnt, profLds);
+			trace_ray<-1, COUNT>(F, S, world, planeRayIndex, seen, out, cnt, prof);
 		} else {
-			trace_ray<1, COUNT>(F, S, world, planeRayIndex, seen, out, cnt, profLds);
+			trace_ray<1, COUNT>(F, S, world, planeRayIndex, seen, out, cnt, prof);
 		}
 	}
 
 	// WriteSkybox / WriteSkyboxFull (:699-716) for the whole wave: every pixel
 	// of [omin, omax] not marked seen gets the skybox colour.
-	CVX_SEC(8);
+	CVX_BEGIN();
 	unsigned int skyPixels = 0;
 	for (int w = omin >> 5; w <= (omax >> 5); w++) {
 		uint32_t todo = ~seen[w * CVX_WAVE] & range_mask(w, omin, omax);
@@ -831,8 +867,18 @@ __global__ __launch_bounds__(CVX_WAVE) void render_kernel(const DevFrame *__rest
 	}
 
 #ifdef CVX_PROFILE_SECTIONS
-	CVX_SEC(0);
-	if (lane < 16) { atomicAdd(&g_sectionCycles[lane], (unsigned long long)profLds[lane]); }
+	CVX_END(8);
+	for (int i = 0; i < CVX_NSEC; i++) {
+		unsigned int mx = prof.acc[i], sum = prof.acc[i] >> 6;
+		for (int o = 32; o > 0; o >>= 1) {
+			mx = max(mx, (unsigned int)__shfl_xor((int)mx, o));
+			sum += (unsigned int)__shfl_xor((int)sum, o);
+		}
+		if (lane == 0) {
+			atomicAdd(&g_sectionCycles[i], (unsigned long long)mx);
+			atomicAdd(&g_sectionCycles[16 + i], (unsigned long long)sum);
+		}
+	}
 #endif
 	if (COUNT) {
 		cnt.P += skyPixels;

@@ -28,7 +28,7 @@ EXPORTS = [
     "cvx_set_buffer_count", "cvx_draw_segments", "cvx_draw_segments_batch", "cvx_set_shard", "cvx_synchronize",
     "cvx_clear_raybuffer", "cvx_read_raybuffer", "cvx_blit_segments", "cvx_raybuffer_device_ptr",
     "cvx_screen_device_ptr", "cvx_last_draw_ms", "cvx_enable_counters", "cvx_get_counters",
-    "cvx_get_raybuffer_layout", "cvx_selftest_math", "cvx_version", "cvx_bind_raybuffers", "cvx_draw_time_stats", "cvx_debug_section_cycles",
+    "cvx_get_raybuffer_layout", "cvx_selftest_math", "cvx_version", "cvx_bind_raybuffers", "cvx_draw_time_stats", "cvx_debug_section_cycles", "cvx_debug_occupancy",
 ]
 
 
@@ -255,9 +255,15 @@ class Context:
         self._check(lib().cvx_get_raybuffer_layout(self._h, which, C.byref(out)))
         return out
 
+    def debug_occupancy(self, lds_bytes: int) -> int:
+        n = C.c_int()
+        lib().cvx_debug_occupancy.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int)]
+        self._check(lib().cvx_debug_occupancy(self._h, lds_bytes, C.byref(n)))
+        return n.value
+
     def debug_section_cycles(self, reset: bool = False):
         """Diagnostic build only: wave cycles per render-kernel section (include/cpuvox_gpu.h)."""
-        out = (C.c_uint64 * 16)()
+        out = (C.c_uint64 * 32)()
         self._check(lib().cvx_debug_section_cycles(self._h, out, int(reset)))
         return list(out)
 

@@ -189,11 +189,14 @@ typedef struct cvx_raybuffer_layout {
 } cvx_raybuffer_layout;
 int cvx_get_raybuffer_layout(cvx_context *ctx, int which, cvx_raybuffer_layout *out);
 
+/* Resident render-kernel workgroups (= waves) per CU the runtime predicts for a given dynamic LDS size. */
+int cvx_debug_occupancy(cvx_context *ctx, int64_t ldsBytes, int *blocksPerCU);
+
 /* Diagnostic build only (make gpu-prof, -DCVX_PROFILE_SECTIONS): wave cycles spent per code section of the
  * render kernel (s_memtime stamps), accumulated over all launches.  Sections: 0 prologue/epilogue, 1 phase A
  * (DDA step + header + cull), 2 frustum clip, 3 element walk, 4 side-face setup, 5 side-face pixels,
  * 6 top/bottom setup, 7 top/bottom pixels, 8 skybox pass.  The regular build returns CVX_ERR_NOT_READY. */
-int cvx_debug_section_cycles(cvx_context *ctx, uint64_t out[16], int reset);
+int cvx_debug_section_cycles(cvx_context *ctx, uint64_t out[32], int reset); /* [16+i] = cycles/16 * active lanes of section i */
 
 /* Arithmetic self-test hook used by tests: evaluates op on n float pairs on
  * the device.  op: 0 a/b, 1 sqrt(a), 2 1/sqrt(a), 3 a*b+c style lerp a+b*(b-a),

@@ -10,7 +10,7 @@ os.environ.setdefault("CVX_GPU_LIB", os.path.join(ROOT, "cpuvox_amd", "libcpuvox
 
 from cpuvox_amd import gpu, host  # noqa: E402
 
-NAMES = ["prologue/epilogue", "phase A (DDA+header+cull)", "frustum clip", "element walk", "side setup", "side pixels",
+NAMES = ["(unused)", "look-ahead + cull", "frustum clip", "element walk", "side setup", "side pixels",
          "top/bottom setup", "top/bottom pixels", "skybox pass"]
 
 ap = argparse.ArgumentParser()
@@ -34,5 +34,7 @@ ctx.draw_segments_batch(frames, 0)
 cyc = ctx.debug_section_cycles()
 total = sum(cyc[:9])
 print(f"kernel {ctx.last_draw_ms():.2f} ms for {args.frames} frames (instrumented build; read the shares, not the time)")
-for n, c in zip(NAMES, cyc):
-    print(f"{n:28s} {c:16d} {100.0 * c / total:6.2f} %")
+for i, (n, c) in enumerate(zip(NAMES, cyc)):
+    lanes = 64.0 * cyc[16 + i] / max(1, c)
+    print(f"{n:28s} {c:16d} {100.0 * c / total:6.2f} %   mean active lanes {lanes:5.1f}")
+print(f"overall mean active lanes {64.0 * sum(cyc[16:25]) / total:5.1f} of 64")
