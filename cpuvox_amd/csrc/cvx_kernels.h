@@ -339,6 +339,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 	const int maskX = world->maskX, maskZ = world->maskZ;
 	const float worldMaxY = (float)world->dimY;
 	const float cameraPosYNormalized = posY / worldMaxY;
+	const float invWorldMaxY = 1.0f / worldMaxY; // exact: dimY is a power of two
 
 	int nextFreePixelMin = omin;
 	int nextFreePixelMax = omax;
@@ -555,8 +556,10 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 				break;
 			}
 
-			const float portionBottom = (elementBoundsMin - 0.0f) / (worldMaxY - 0.0f); // unlerp(0, worldMaxY, x)
-			const float portionTop = (elementBoundsMax - 0.0f) / (worldMaxY - 0.0f);
+			// unlerp(0, worldMaxY, x) = (x - 0) / (worldMaxY - 0); worldMaxY is a power of two (enforced at upload), so
+			// multiplying by its exact reciprocal gives the identical correctly rounded quotient
+			const float portionBottom = elementBoundsMin * invWorldMaxY;
+			const float portionTop = elementBoundsMax * invWorldMaxY;
 			f3 camSpaceFrontBottom = f3_lerp(camSpaceMinLast, camSpaceMaxLast, portionBottom);
 			f3 camSpaceFrontTop = f3_lerp(camSpaceMinLast, camSpaceMaxLast, portionTop);
 
@@ -803,7 +806,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 // render kernel: grid = tiles, block = 64 (one wave).  LDS: words*64 uint32.
 // ---------------------------------------------------------------------------
 template <bool COUNT>
-__global__ __launch_bounds__(CVX_WAVE) void render_kernel(const DevFrame *__restrict__ frames, const DevTile *__restrict__ tiles,
+__global__ __launch_bounds__(CVX_WAVE, 4) void render_kernel(const DevFrame *__restrict__ frames, const DevTile *__restrict__ tiles,
                                                           const DevWorld *__restrict__ world, DevCounters *__restrict__ counters)
 {
 	extern __shared__ uint32_t lds[];
