@@ -122,7 +122,8 @@ def main():
         lay_td, lay_lr = ctx.raybuffer_layout(0), ctx.raybuffer_layout(1)
         pools = cdist.allocate_pools(G, lay_td, lay_lr, device)
         ctx.bind_raybuffers(pools.td.data_ptr(), pools.td.numel() * 4, pools.lr.data_ptr(), pools.lr.numel() * 4)
-        exchange = [cdist.TileExchange(frames, W, H, rank, N, pools, device) for frames in steps_frames]
+        exchange = [cdist.TileExchange(frames, W, H, rank, N, pools, device, ctx) for frames in steps_frames]
+        cdist.TileExchange.allocate_staging(exchange, device)
     packed = [ctx.pack_batch(frames) for frames in steps_frames]
     rays_per_step = [sum(f.totalRays for f in frames) for frames in steps_frames]
 
@@ -215,7 +216,7 @@ def main():
         },
     }
 
-    if rank == 0 and args.cpu_seconds > 0:
+    if rank == 0 and N == 1 and args.cpu_seconds > 0:  # the CPU baseline is reported at N = 1 only
         result["cpu_baseline"] = cpu_baseline(ws, steps_frames[args.warmup], W, H, args.cpu_seconds)
     if rank == 0:
         print(json.dumps(result), flush=True)

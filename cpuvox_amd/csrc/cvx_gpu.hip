@@ -154,6 +154,23 @@ bool Finite(const float *v, int n)
 	return true;
 }
 
+// All buffers of one kind live back to back in ONE allocation (buffer b at b * poolBytes), so a consumer can view
+// them as one [bufferCount * tiles, width * 64] array (RCCL exchange of tiles).
+int EnsurePools(cvx_context *ctx)
+{
+	if (ctx->poolBaseTD) { return CVX_OK; }
+	CVX_HIP(ctx, hipSetDevice(ctx->device));
+	CVX_HIP(ctx, hipMalloc((void **)&ctx->poolBaseTD, ctx->poolBytesTD * (size_t)ctx->bufferCount));
+	CVX_HIP(ctx, hipMalloc((void **)&ctx->poolBaseLR, ctx->poolBytesLR * (size_t)ctx->bufferCount));
+	CVX_HIP(ctx, hipMemsetAsync(ctx->poolBaseTD, 0, ctx->poolBytesTD * (size_t)ctx->bufferCount, ctx->stream));
+	CVX_HIP(ctx, hipMemsetAsync(ctx->poolBaseLR, 0, ctx->poolBytesLR * (size_t)ctx->bufferCount, ctx->stream));
+	for (int i = 0; i < ctx->bufferCount; i++) {
+		ctx->poolTD[(size_t)i] = ctx->poolBaseTD + (size_t)i * (ctx->poolBytesTD / 4);
+		ctx->poolLR[(size_t)i] = ctx->poolBaseLR + (size_t)i * (ctx->poolBytesLR / 4);
+	}
+	return CVX_OK;
+}
+
 int EnsureScratch(cvx_context *ctx, size_t frames, size_t tiles)
 {
 	if (frames > ctx->devFramesCap) {
@@ -599,16 +616,8 @@ int cvx_set_resolution(cvx_context *ctx, int resolutionX, int resolutionY)
 	ctx->poolTD.assign((size_t)ctx->bufferCount, nullptr);
 	ctx->poolLR.assign((size_t)ctx->bufferCount, nullptr);
 	ctx->last.assign((size_t)ctx->bufferCount, LastDraw());
-	// all buffers of one kind live back to back in ONE allocation (buffer b at b * poolBytes), so a
-	// consumer can view them as one [bufferCount * tiles, width * 64] array (RCCL exchange of tiles)
-	CVX_HIP(ctx, hipMalloc((void **)&ctx->poolBaseTD, ctx->poolBytesTD * (size_t)ctx->bufferCount));
-	CVX_HIP(ctx, hipMalloc((void **)&ctx->poolBaseLR, ctx->poolBytesLR * (size_t)ctx->bufferCount));
-	CVX_HIP(ctx, hipMemsetAsync(ctx->poolBaseTD, 0, ctx->poolBytesTD * (size_t)ctx->bufferCount, ctx->stream));
-	CVX_HIP(ctx, hipMemsetAsync(ctx->poolBaseLR, 0, ctx->poolBytesLR * (size_t)ctx->bufferCount, ctx->stream));
-	for (int i = 0; i < ctx->bufferCount; i++) {
-		ctx->poolTD[(size_t)i] = ctx->poolBaseTD + (size_t)i * (ctx->poolBytesTD / 4);
-		ctx->poolLR[(size_t)i] = ctx->poolBaseLR + (size_t)i * (ctx->poolBytesLR / 4);
-	}
+	// the pools themselves are allocated on first use (EnsurePools) so that cvx_bind_raybuffers can supply
+	// caller-owned memory without a transient second copy
 	CVX_HIP(ctx, hipMalloc((void **)&ctx->screen, (size_t)W * (size_t)H * 4));
 	CVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	ctx->resX = W;
@@ -662,7 +671,9 @@ int cvx_draw_segments_batch(cvx_context *ctx, int frameCount, const cvx_segment_
 		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "buffer index %d / %d frames do not fit bufferCount %d", firstBufferIndex, frameCount, ctx->bufferCount);
 	}
 	CVX_HIP(ctx, hipSetDevice(ctx->device));
-	int rc = SyncWorld(ctx);
+	int rc = EnsurePools(ctx);
+	if (rc != CVX_OK) { return rc; }
+	rc = SyncWorld(ctx);
 	if (rc != CVX_OK) { return rc; }
 	ctx->hostFrames.assign((size_t)frameCount, DevFrame());
 	ctx->hostTiles.clear();
@@ -760,6 +771,7 @@ int cvx_clear_raybuffer(cvx_context *ctx, int bufferIndex, int which, uint32_t a
 		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "bad buffer selection");
 	}
 	CVX_HIP(ctx, hipSetDevice(ctx->device));
+	{ int rc = EnsurePools(ctx); if (rc != CVX_OK) { return rc; } }
 	uint32_t *p = which == 0 ? ctx->poolTD[(size_t)bufferIndex] : ctx->poolLR[(size_t)bufferIndex];
 	size_t bytes = which == 0 ? ctx->poolBytesTD : ctx->poolBytesLR;
 	CVX_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)p, (int)argb, bytes / 4, ctx->stream));
@@ -778,6 +790,7 @@ int cvx_read_raybuffer(cvx_context *ctx, int bufferIndex, int which, int firstRa
 	if (firstRay < 0 || rayCount < 0 || firstRay + rayCount > capacity) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "ray range outside the buffer"); }
 	if (rayCount == 0) { return CVX_OK; }
 	CVX_HIP(ctx, hipSetDevice(ctx->device));
+	{ int rc = EnsurePools(ctx); if (rc != CVX_OK) { return rc; } }
 	const size_t bytes = (size_t)rayCount * (size_t)width * 4;
 	if (bytes > ctx->stagingBytes) {
 		if (ctx->staging) { (void)hipFree(ctx->staging); ctx->staging = nullptr; ctx->stagingBytes = 0; }
@@ -835,6 +848,7 @@ int cvx_raybuffer_device_ptr(cvx_context *ctx, int bufferIndex, int which, void 
 	if (ctx->poolTD.empty() || bufferIndex < 0 || bufferIndex >= ctx->bufferCount || (which != 0 && which != 1) || !ptr) {
 		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "bad buffer selection");
 	}
+	{ int rc = EnsurePools(ctx); if (rc != CVX_OK) { return rc; } }
 	*ptr = which == 0 ? ctx->poolTD[(size_t)bufferIndex] : ctx->poolLR[(size_t)bufferIndex];
 	if (bytes) { *bytes = (int64_t)(which == 0 ? ctx->poolBytesTD : ctx->poolBytesLR); }
 	return CVX_OK;
@@ -910,6 +924,23 @@ int cvx_get_raybuffer_layout(cvx_context *ctx, int which, cvx_raybuffer_layout *
 	out->tileRays = CVX_WAVE;
 	out->tileCapacity = which == 0 ? ctx->tilesTD : ctx->tilesLR;
 	out->tileBytes = (int64_t)out->width * CVX_WAVE * 4;
+	return CVX_OK;
+}
+
+int cvx_copy_rows(cvx_context *ctx, void *hipStream, int toPacked, int64_t spanCount, const cvx_row_span *spansDevice, void *packedDevice)
+{
+	static_assert(sizeof(cvx_row_span) == sizeof(cvxk::RowSpan), "span layout");
+	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
+	if (ctx->poolTD.empty()) { return Fail(ctx, CVX_ERR_NOT_READY, "resolution not set"); }
+	if (spanCount < 0 || (spanCount > 0 && (!spansDevice || !packedDevice))) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "bad span arguments"); }
+	if (spanCount == 0) { return CVX_OK; }
+	CVX_HIP(ctx, hipSetDevice(ctx->device));
+	{ int rc = EnsurePools(ctx); if (rc != CVX_OK) { return rc; } }
+	hipStream_t st = hipStream ? (hipStream_t)hipStream : ctx->stream;
+	hipLaunchKernelGGL(cvxk::copy_rows_kernel, dim3((unsigned)spanCount), dim3(256), 0, st, reinterpret_cast<uint4 *>(ctx->poolBaseTD),
+	                   reinterpret_cast<uint4 *>(ctx->poolBaseLR), static_cast<uint4 *>(packedDevice),
+	                   reinterpret_cast<const cvxk::RowSpan *>(spansDevice), toPacked);
+	CVX_HIP(ctx, hipGetLastError());
 	return CVX_OK;
 }
 

@@ -927,6 +927,34 @@ __global__ void untile_kernel(const uint32_t *__restrict__ pool, uint32_t *__res
 }
 
 // ---------------------------------------------------------------------------
+// copy_rows: pack / unpack pixel rows of tiles (one row = 64 pixels = 256 bytes) between the tile pools and a
+// contiguous staging buffer -- the payload of the multi-GPU tile exchange is only the rows [origMin, origMax]
+// a segment can write.  One workgroup per span, 16 bytes per thread.
+// ---------------------------------------------------------------------------
+struct RowSpan { // == cvx_row_span
+	long long poolRow;   // first row inside the pool (in 256-byte rows)
+	long long packedRow; // first row inside the staging buffer
+	int rows;
+	int kind;            // 0 top-down pool, 1 left-right pool
+};
+
+__global__ void copy_rows_kernel(uint4 *__restrict__ poolTD, uint4 *__restrict__ poolLR, uint4 *__restrict__ packed,
+                                 const RowSpan *__restrict__ spans, int toPacked)
+{
+	const RowSpan sp = spans[blockIdx.x];
+	uint4 *pool = (sp.kind == 0 ? poolTD : poolLR) + sp.poolRow * 16;
+	uint4 *stage = packed + sp.packedRow * 16;
+	const long long n = (long long)sp.rows * 16; // uint4 per span
+	for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+		if (toPacked) {
+			stage[i] = pool[i];
+		} else {
+			pool[i] = stage[i];
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------
 // Phase 2: RenderManager.BlitSegments (RenderManager.cs:199-256) +
 // RayBufferBlit.shader frag (:48-64), evaluated at pixel centres.  Rule (ours,
 // Unity's rasteriser is not restated): barycentrics of the centre in triangle

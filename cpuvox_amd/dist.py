@@ -1,22 +1,28 @@
 """Multi-GPU plumbing for the sharded renderer.
 
 The reference has no distributed code at all; this is the MI355X-side design:
-  * the world LOD chain is replicated on every GPU (read-only, < 0.5 GB at 2048^3),
+  * the world LOD chain is replicated on every GPU (read-only, < 1 GB at 2048^3),
   * every frame's 64-ray tiles are dealt round-robin to the ranks (cvx_set_shard),
   * after rendering, the tiles of frame f are sent to its display rank f % N.
-The exchange is a set of direct peer-to-peer sends (torch.distributed batch_isend_irecv =
-grouped ncclSend/ncclRecv on RCCL), one message per (source, destination) pair and raybuffer kind, so on
-MI355X each pair rides its own xGMI link and no ring is formed.  torch is used for device memory and the
-collective only; tensors may be CPU tensors with the gloo backend (tests).
+The exchange is a set of direct peer-to-peer transfers (torch.distributed batch_isend_irecv = grouped
+ncclSend/ncclRecv on RCCL), one message per (source, destination) pair, so on MI355X each pair rides its own
+xGMI link and no ring is formed.  Only the pixel rows a segment can write ([origMin, origMax] of every tile) travel:
+they are packed into one staging buffer per step by a HIP kernel of libcpuvox_gpu (cvx_copy_rows) and unpacked on
+the receiving side.  torch is used for device memory and the collective only; with CPU tensors (gloo, tests) the
+pack / unpack falls back to numpy.
 """
 from __future__ import annotations
 
 from dataclasses import dataclass
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
 TILE_RAYS = 64
+
+# == cvx_row_span (include/cpuvox_gpu.h)
+SPAN_DTYPE = np.dtype([("poolRow", "<i8"), ("packedRow", "<i8"), ("rows", "<i4"), ("kind", "<i4")])
 
 
 @dataclass
@@ -42,66 +48,130 @@ def allocate_pools(buffer_count: int, lay_td, lay_lr, device) -> Pools:
 
 def frame_tiles(ray_counts):
     """Tiles of one frame in the order libcpuvox_gpu numbers them (segment-major): list of (kind, tile index in
-    the buffer's pool); kind 0 = top-down pool (segments 0,1), 1 = left-right pool (segments 2,3)."""
+    the buffer's pool, segment); kind 0 = top-down pool (segments 0,1), 1 = left-right pool (segments 2,3)."""
     out = []
     base = [0, 0]
     for s in range(4):
         kind = 0 if s < 2 else 1
-        if s == 2:
-            base[1] = 0
         n = (max(0, ray_counts[s]) + TILE_RAYS - 1) // TILE_RAYS
         first = base[kind]
         for t in range(n):
-            out.append((kind, first + t))
+            out.append((kind, first + t, s))
         base[kind] = first + n
     return out
+
+
+def segment_pixel_ranges(vp, width: int, height: int):
+    """[originalNextFreePixelMin, Max] of the four segments (RenderManager.cs:298-316; Mathf.RoundToInt = half to even)."""
+    def rnd(v, hi):
+        r = float(np.rint(np.float32(v)))
+        if not np.isfinite(r):
+            r = -2147483648.0
+        return int(min(max(r, 0), hi))
+
+    vx, vy = rnd(vp[0], width - 1), rnd(vp[1], height - 1)
+    return [(vy, height - 1), (0, vy), (vx, width - 1), (0, vx)]
 
 
 class TileExchange:
     """Precomputed exchange for one batch of frames: rank r rendered the tiles t of every frame with
     t % N == r into buffer b = frame index; afterwards frame f must be complete on rank f % N."""
 
-    def __init__(self, frames, width: int, height: int, rank: int, world_size: int, pools: Pools, device):
-        self.rank, self.N, self.pools = rank, world_size, pools
+    def __init__(self, frames, width: int, height: int, rank: int, world_size: int, pools: Pools, device, ctx=None):
+        self.rank, self.N, self.pools, self.ctx = rank, world_size, pools, ctx
+        self.device = torch.device(device)
         N = world_size
-        send = [[[], []] for _ in range(N)]  # [dest][kind] -> pool rows
-        recv = [[[], []] for _ in range(N)]  # [src][kind]
         caps = (pools.tiles_td, pools.tiles_lr)
+        col = (height, width)
+        send = [[] for _ in range(N)]  # per peer: (kind, poolRow, rows)
+        recv = [[] for _ in range(N)]
         for b, fr in enumerate(frames):
-            rc = [s.RayCount for s in fr.segments] if hasattr(fr, "segments") else list(fr)
+            if hasattr(fr, "segments"):
+                rc = [s.RayCount for s in fr.segments]
+                ranges = segment_pixel_ranges(fr.vanishingPointScreenSpace, width, height)
+            else:  # (rayCounts, vanishingPoint) tuples
+                rc, vp = fr
+                ranges = segment_pixel_ranges(vp, width, height)
             root = b % N
-            for t, (kind, tile) in enumerate(frame_tiles(rc)):
+            for t, (kind, tile, seg) in enumerate(frame_tiles(rc)):
                 owner = t % N
-                row = b * caps[kind] + tile
-                if owner == rank and root != rank:
-                    send[root][kind].append(row)
-                elif owner != rank and root == rank:
-                    recv[owner][kind].append(row)
-        self.ops_spec = []
-        for kind, pool in ((0, pools.td), (1, pools.lr)):
-            for peer in range(N):
-                if peer == rank:
+                if owner == root or (owner != rank and root != rank):
                     continue
-                s_rows = torch.tensor(send[peer][kind], dtype=torch.long, device=device)
-                r_rows = torch.tensor(recv[peer][kind], dtype=torch.long, device=device)
-                s_buf = torch.empty((len(send[peer][kind]), pool.shape[1]), dtype=pool.dtype, device=device) if len(send[peer][kind]) else None
-                r_buf = torch.empty((len(recv[peer][kind]), pool.shape[1]), dtype=pool.dtype, device=device) if len(recv[peer][kind]) else None
-                self.ops_spec.append((pool, peer, s_rows, s_buf, r_rows, r_buf))
-        self.sent_rows = sum(len(send[p][k]) for p in range(N) for k in range(2))
-        self.recv_rows = sum(len(recv[p][k]) for p in range(N) for k in range(2))
+                lo, hi = ranges[seg]
+                item = (kind, (b * caps[kind] + tile) * col[kind] + lo, hi - lo + 1)
+                if owner == rank:
+                    send[root].append(item)
+                else:
+                    recv[owner].append(item)
+
+        def layout(lists):
+            spans = []
+            offsets = [0]
+            for peer in range(N):
+                row = offsets[-1]
+                for kind, pool_row, rows in lists[peer]:
+                    spans.append((pool_row, row, rows, kind))
+                    row += rows
+                offsets.append(row)
+            arr = np.array(spans, dtype=SPAN_DTYPE) if spans else np.zeros(0, dtype=SPAN_DTYPE)
+            return arr, offsets
+
+        self.send_spans, self.send_off = layout(send)
+        self.recv_spans, self.recv_off = layout(recv)
+        self.sent_rows, self.recv_rows = self.send_off[-1], self.recv_off[-1]
+        self.payload_bytes = (self.sent_rows + self.recv_rows) * TILE_RAYS * 4
+        if self.device.type == "cuda":
+            self._send_spans_dev = torch.from_numpy(self.send_spans.view(np.uint8).copy()).to(self.device)
+            self._recv_spans_dev = torch.from_numpy(self.recv_spans.view(np.uint8).copy()).to(self.device)
+
+    # staging buffers are shared by all exchanges of a run (sized for the largest)
+    @staticmethod
+    def allocate_staging(exchanges, device):
+        rows_s = max((e.sent_rows for e in exchanges), default=0)
+        rows_r = max((e.recv_rows for e in exchanges), default=0)
+        send = torch.empty((max(1, rows_s), TILE_RAYS), dtype=torch.int32, device=device)
+        recv = torch.empty((max(1, rows_r), TILE_RAYS), dtype=torch.int32, device=device)
+        for e in exchanges:
+            e.send_buf, e.recv_buf = send, recv
+        return send, recv
+
+    def _copy_rows(self, spans, spans_dev, staging, to_packed: bool) -> None:
+        if len(spans) == 0:
+            return
+        if self.device.type == "cuda":
+            if self.ctx is None:
+                raise RuntimeError("TileExchange on GPU tensors needs the cpuvox_amd.gpu.Context that owns the pools")
+            self.ctx.copy_rows(None, to_packed, len(spans), spans_dev.data_ptr(), staging.data_ptr())
+            self.ctx.synchronize()
+            return
+        rows = (self.pools.td.view(-1, TILE_RAYS).numpy(), self.pools.lr.view(-1, TILE_RAYS).numpy())
+        stage = staging.numpy()
+        for sp in spans:
+            a, p, n, k = int(sp["poolRow"]), int(sp["packedRow"]), int(sp["rows"]), int(sp["kind"])
+            if to_packed:
+                stage[p:p + n] = rows[k][a:a + n]
+            else:
+                rows[k][a:a + n] = stage[p:p + n]
 
     def run(self) -> None:
-        """Pack my tiles per destination, exchange, scatter the received tiles into their pool rows."""
+        """Pack my tiles' pixel rows per destination, exchange, unpack the received rows into their pool places.
+        The caller orders this after the render (ctx.synchronize()) and before the next one."""
+        if not hasattr(self, "send_buf"):
+            TileExchange.allocate_staging([self], self.device)
+        self._copy_rows(self.send_spans, getattr(self, "_send_spans_dev", None), self.send_buf, True)
         ops = []
-        for pool, peer, s_rows, s_buf, r_rows, r_buf in self.ops_spec:
-            if s_buf is not None:
-                torch.index_select(pool, 0, s_rows, out=s_buf)
-                ops.append(dist.P2POp(dist.isend, s_buf, peer))
-            if r_buf is not None:
-                ops.append(dist.P2POp(dist.irecv, r_buf, peer))
+        for peer in range(self.N):
+            if peer == self.rank:
+                continue
+            s0, s1 = self.send_off[peer], self.send_off[peer + 1]
+            r0, r1 = self.recv_off[peer], self.recv_off[peer + 1]
+            if s1 > s0:
+                ops.append(dist.P2POp(dist.isend, self.send_buf[s0:s1], peer))
+            if r1 > r0:
+                ops.append(dist.P2POp(dist.irecv, self.recv_buf[r0:r1], peer))
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
-        for pool, peer, s_rows, s_buf, r_rows, r_buf in self.ops_spec:
-            if r_buf is not None:
-                pool.index_copy_(0, r_rows, r_buf)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        self._copy_rows(self.recv_spans, getattr(self, "_recv_spans_dev", None), self.recv_buf, False)

@@ -28,7 +28,7 @@ EXPORTS = [
     "cvx_set_buffer_count", "cvx_draw_segments", "cvx_draw_segments_batch", "cvx_set_shard", "cvx_synchronize",
     "cvx_clear_raybuffer", "cvx_read_raybuffer", "cvx_blit_segments", "cvx_raybuffer_device_ptr",
     "cvx_screen_device_ptr", "cvx_last_draw_ms", "cvx_enable_counters", "cvx_get_counters",
-    "cvx_get_raybuffer_layout", "cvx_selftest_math", "cvx_version", "cvx_bind_raybuffers", "cvx_draw_time_stats", "cvx_debug_section_cycles", "cvx_debug_occupancy",
+    "cvx_get_raybuffer_layout", "cvx_selftest_math", "cvx_version", "cvx_bind_raybuffers", "cvx_draw_time_stats", "cvx_debug_section_cycles", "cvx_debug_occupancy", "cvx_copy_rows",
 ]
 
 
@@ -90,6 +90,7 @@ def lib() -> C.CDLL:
         L.cvx_get_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
         L.cvx_get_raybuffer_layout.argtypes = [C.c_void_p, C.c_int, C.POINTER(RaybufferLayout)]
         L.cvx_bind_raybuffers.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
+        L.cvx_copy_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
         L.cvx_debug_section_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
         L.cvx_selftest_math.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
@@ -249,6 +250,10 @@ class Context:
     def bind_raybuffers(self, td_ptr: int, td_bytes: int, lr_ptr: int, lr_bytes: int) -> None:
         """Render into caller-owned device memory (e.g. torch tensors used by a RCCL exchange)."""
         self._check(lib().cvx_bind_raybuffers(self._h, C.c_void_p(td_ptr), td_bytes, C.c_void_p(lr_ptr), lr_bytes))
+
+    def copy_rows(self, hip_stream: int | None, to_packed: bool, span_count: int, spans_ptr: int, packed_ptr: int) -> None:
+        """Pack / unpack tile pixel rows between the pools and a staging buffer (multi-GPU exchange payload)."""
+        self._check(lib().cvx_copy_rows(self._h, C.c_void_p(hip_stream or 0), int(to_packed), span_count, C.c_void_p(spans_ptr), C.c_void_p(packed_ptr)))
 
     def raybuffer_layout(self, which: int) -> RaybufferLayout:
         out = RaybufferLayout()

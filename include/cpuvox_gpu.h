@@ -164,6 +164,18 @@ int cvx_blit_segments(cvx_context *ctx, int bufferIndex, void *dstHost);
  * frees bound memory; call after cvx_set_resolution (which allocates internal ones). */
 int cvx_bind_raybuffers(cvx_context *ctx, void *topDown, int64_t topDownBytes, void *leftRight, int64_t leftRightBytes);
 
+/* Multi-GPU tile exchange helper: copies pixel rows (one row = 64 pixels of a tile = 256 bytes) between the
+ * raybuffer pools of this context and a contiguous device staging buffer.  poolRow counts 256-byte rows from the start
+ * of the pool (all buffers back to back): ((buffer * tileCapacity + tile) * width + pixelRow).  The span array lives in
+ * device memory; hipStream NULL = the context's stream.  toPacked != 0: pool -> staging, else staging -> pool. */
+typedef struct cvx_row_span {
+	int64_t poolRow;
+	int64_t packedRow;
+	int32_t rows;
+	int32_t kind; /* CVX_RAYBUFFER_TOPDOWN / CVX_RAYBUFFER_LEFTRIGHT */
+} cvx_row_span;
+int cvx_copy_rows(cvx_context *ctx, void *hipStream, int toPacked, int64_t spanCount, const cvx_row_span *spansDevice, void *packedDevice);
+
 /* Device pointers for zero-copy consumers (RCCL gather, torch tensors). */
 int cvx_raybuffer_device_ptr(cvx_context *ctx, int bufferIndex, int which, void **ptr, int64_t *bytes);
 int cvx_screen_device_ptr(cvx_context *ctx, void **ptr, int64_t *bytes);

@@ -59,7 +59,7 @@ def _worker(rank, world_size, port, result_queue):
             ptd, plr = _tile_major(fr, td, lr, tiles_td, tiles_lr)
             full.append((ptd, plr))
             rc = [s.RayCount for s in fr.segments]
-            for t, (kind, tile) in enumerate(cdist.frame_tiles(rc)):
+            for t, (kind, tile, _seg) in enumerate(cdist.frame_tiles(rc)):
                 if t % world_size == rank:  # what cvx_set_shard(rank, N) renders on this rank
                     if kind == 0:
                         pools.td[b * tiles_td + tile] = torch.from_numpy(ptd[tile].view(np.int32))
@@ -96,9 +96,17 @@ def test_tile_exchange_world_size_2_gloo():
     assert results[0][2] == results[1][3] and results[1][2] == results[0][3] and results[0][2] > 0
 
 
+def test_only_writable_rows_travel():
+    """The payload of a tile is rows [origMin, origMax] of its segment, not the whole tile."""
+    ranges = cdist.segment_pixel_ranges((100.4, 50.5), 320, 200)
+    assert ranges == [(50, 199), (0, 50), (100, 319), (0, 100)]  # RoundToInt(50.5) = 50 (half to even)
+    assert cdist.segment_pixel_ranges((-5000.0, 1e9), 320, 200) == [(199, 199), (0, 199), (0, 319), (0, 0)]
+
+
 def test_frame_tiles_matches_the_library_numbering():
     """frame_tiles() mirrors BuildFrame() in cvx_gpu.hip: segment-major, segment 1/3 tiles follow 0/2 in their pool."""
     tiles = cdist.frame_tiles([130, 64, 0, 65])
-    assert tiles == [(0, 0), (0, 1), (0, 2), (0, 3), (1, 0), (1, 1)]
+    assert [(k, t) for k, t, _ in tiles] == [(0, 0), (0, 1), (0, 2), (0, 3), (1, 0), (1, 1)]
+    assert [s for _, _, s in tiles] == [0, 0, 0, 1, 3, 3]
     assert cdist.frame_tiles([0, 0, 0, 0]) == []
     assert cdist.tile_capacity(1920, 1080) == ((1920 + 2160 + 63) // 64 + 2, (3840 + 1080 + 63) // 64 + 2)

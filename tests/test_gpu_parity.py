@@ -193,3 +193,44 @@ def test_errors_are_reported_not_swallowed():
     with pytest.raises(gpu.CvxError):  # non-finite camera
         ctx.draw_segments(fr, 0)
     ctx.close()
+
+
+def test_copy_rows_pack_unpack_round_trip(contexts):
+    """cvx_copy_rows (payload packing of the multi-GPU tile exchange): pool -> staging -> pool restores the rows."""
+    import torch
+
+    from cpuvox_amd import dist as cdist
+
+    name = "proc256_t075_lod8"
+    ws, fr, W, H = scenes.scene_frame(name)
+    ctx = gpu.Context(0, buffer_count=2)
+    ctx.upload_world(ws)
+    ctx.set_resolution(W, H)
+    lay_td, lay_lr = ctx.raybuffer_layout(0), ctx.raybuffer_layout(1)
+    dev = torch.device("cuda", 0)
+    pools = cdist.allocate_pools(2, lay_td, lay_lr, dev)
+    ctx.bind_raybuffers(pools.td.data_ptr(), pools.td.numel() * 4, pools.lr.data_ptr(), pools.lr.numel() * 4)
+    ctx.draw_segments(fr, 1)
+    ctx.synchronize()
+    # "rank 1 of 2" view: what it would send to rank 0 for a frame in buffer 0 ... use buffer 1 -> root 1, owner 0 sends
+    ex = cdist.TileExchange([fr, fr], W, H, 0, 2, pools, dev, ctx)
+    assert ex.sent_rows > 0 and ex.recv_rows > 0
+    cdist.TileExchange.allocate_staging([ex], dev)
+    before_td, before_lr = pools.td.clone(), pools.lr.clone()
+    ex._copy_rows(ex.send_spans, ex._send_spans_dev, ex.send_buf, True)
+    # staging holds exactly the spans' rows
+    rows_td = pools.td.view(-1, 64)
+    rows_lr = pools.lr.view(-1, 64)
+    for sp in ex.send_spans[:: max(1, len(ex.send_spans) // 7)]:
+        src = (rows_td if sp["kind"] == 0 else rows_lr)[int(sp["poolRow"]): int(sp["poolRow"]) + int(sp["rows"])]
+        assert torch.equal(ex.send_buf[int(sp["packedRow"]): int(sp["packedRow"]) + int(sp["rows"])], src)
+    # wipe the span rows, unpack, compare
+    for sp in ex.send_spans:
+        (rows_td if sp["kind"] == 0 else rows_lr)[int(sp["poolRow"]): int(sp["poolRow"]) + int(sp["rows"])] = 0
+    ex._copy_rows(ex.send_spans, ex._send_spans_dev, ex.send_buf, False)
+    assert torch.equal(pools.td, before_td) and torch.equal(pools.lr, before_lr)
+    # the render through bound (external) pools is still bit exact
+    o_td, o_lr, _ = O.draw_segments(ws, fr, W, H, clear=0, counters=False)
+    n_td, n_lr = scenes.used_rows(fr)
+    assert (ctx.read_raybuffer(1, 0, 0, n_td) == o_td[:n_td]).all() and (ctx.read_raybuffer(1, 1, 0, n_lr) == o_lr[:n_lr]).all()
+    ctx.close()
