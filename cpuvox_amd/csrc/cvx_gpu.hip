@@ -705,9 +705,22 @@ int cvx_draw_segments_batch(cvx_context *ctx, int frameCount, const cvx_segment_
 			bucket[i] = (uint8_t)b;
 		}
 		const std::vector<float> &cost = ctx->hostTileCost;
-		std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-			return bucket[a] != bucket[b] ? bucket[a] < bucket[b] : cost[a] > cost[b];
-		});
+		static const bool frameMajor = getenv("CVX_ORDER_FRAME_MAJOR") && atoi(getenv("CVX_ORDER_FRAME_MAJOR")) != 0; // experiment
+		if (frameMajor) {
+			// frames with the longest tile first; all tiles of a frame adjacent (longest first inside the frame)
+			std::vector<float> frameCost((size_t)frameCount, 0.f);
+			for (size_t i = 0; i < n; i++) { frameCost[(size_t)ctx->hostTiles[i].frame] = std::max(frameCost[(size_t)ctx->hostTiles[i].frame], cost[i]); }
+			std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+				const int fa = ctx->hostTiles[a].frame, fb = ctx->hostTiles[b].frame;
+				if (bucket[a] != bucket[b]) { return bucket[a] < bucket[b]; }
+				if (fa != fb) { return frameCost[(size_t)fa] != frameCost[(size_t)fb] ? frameCost[(size_t)fa] > frameCost[(size_t)fb] : fa < fb; }
+				return cost[a] > cost[b];
+			});
+		} else {
+			std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+				return bucket[a] != bucket[b] ? bucket[a] < bucket[b] : cost[a] > cost[b];
+			});
+		}
 		std::vector<DevTile> sorted(n);
 		for (int b = 0; b <= cvx_context::kBuckets; b++) { ctx->bucketBegin[b] = n; }
 		for (int b = 0; b < cvx_context::kBuckets; b++) { ctx->bucketWords[b] = 1; }

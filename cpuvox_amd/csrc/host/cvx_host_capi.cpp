@@ -9,6 +9,7 @@
 
 #include "cvx_frame.h"
 #include "cvx_mesh.h"
+#include "cvx_render_manager.h"
 #include "cvx_world.h"
 
 struct cvxh_world_set {
@@ -183,6 +184,105 @@ int cvxh_setup_frame(const cvxh_camera_pose *pose, int limitHorizon, float farCl
 	cvx::float3 f = cam.forward();
 	out->forward[0] = f.x; out->forward[1] = f.y; out->forward[2] = f.z;
 	out->totalRays = fs.totalRays;
+	return CVX_OK;
+}
+
+struct cvxh_render_manager {
+	std::unique_ptr<cvx::RenderManager> rm;
+};
+
+int cvxh_render_manager_create(int device, int screenWidth, int screenHeight, const char *gpuLibraryPath, cvxh_render_manager **out)
+{
+	if (!out || !gpuLibraryPath) { return Fail("bad argument"); }
+	try {
+		auto h = std::make_unique<cvxh_render_manager>();
+		h->rm = std::make_unique<cvx::RenderManager>(device, screenWidth, screenHeight, gpuLibraryPath);
+		*out = h.release();
+	} catch (const std::exception &e) {
+		return Fail(e.what());
+	}
+	return CVX_OK;
+}
+
+void cvxh_render_manager_destroy(cvxh_render_manager *rm) { delete rm; }
+
+int cvxh_render_manager_upload_world(cvxh_render_manager *rm, const cvxh_world_set *worlds)
+{
+	if (!rm || !worlds) { return Fail("bad argument"); }
+	try {
+		rm->rm->UploadWorld(worlds->worlds);
+	} catch (const std::exception &e) {
+		return Fail(e.what());
+	}
+	return CVX_OK;
+}
+
+int cvxh_render_manager_set_resolution(cvxh_render_manager *rm, int resolutionX, int resolutionY, int *changed)
+{
+	if (!rm) { return Fail("bad argument"); }
+	try {
+		bool c = rm->rm->SetResolution(resolutionX, resolutionY);
+		if (changed) { *changed = c ? 1 : 0; }
+	} catch (const std::exception &e) {
+		return Fail(e.what());
+	}
+	return CVX_OK;
+}
+
+int cvxh_render_manager_swap_buffers(cvxh_render_manager *rm)
+{
+	if (!rm) { return Fail("bad argument"); }
+	rm->rm->SwapBuffers();
+	return rm->rm->BufferIndex();
+}
+
+int cvxh_render_manager_clear_raybuffer(cvxh_render_manager *rm, int renderMode)
+{
+	if (!rm || renderMode < 0 || renderMode > 2) { return Fail("bad argument"); }
+	try {
+		rm->rm->ClearRayBuffer(static_cast<cvx::ERenderMode>(renderMode));
+	} catch (const std::exception &e) {
+		return Fail(e.what());
+	}
+	return CVX_OK;
+}
+
+int cvxh_render_manager_draw_world(cvxh_render_manager *rm, const cvxh_camera_pose *pose, int limitHorizon, float farClip,
+                                   const float LODDistances[CVX_LOD_LEVELS], uint32_t *screenArgb32, cvxh_frame *outFrame)
+{
+	if (!rm || !pose || !LODDistances) { return Fail("bad argument"); }
+	try {
+		cvx::Camera cam = CameraFromPose(*pose);
+		cam.pixelWidth = rm->rm->ScreenWidth(); // fakeCamera.pixelRect, UnityManager.cs:180
+		cam.pixelHeight = rm->rm->ScreenHeight();
+		cam.farClipPlane = farClip;
+		if (limitHorizon) { cvx::LimitRotationHorizon(cam); }
+		rm->rm->DrawWorld(cam, LODDistances, screenArgb32);
+		if (outFrame) {
+			const cvx::FrameSetup &fs = rm->rm->LastFrame();
+			std::memcpy(outFrame->segments, fs.segments, sizeof fs.segments);
+			outFrame->camera = fs.camera;
+			outFrame->vanishingPointScreenSpace[0] = fs.vanishingPointScreenSpace[0];
+			outFrame->vanishingPointScreenSpace[1] = fs.vanishingPointScreenSpace[1];
+			std::memcpy(outFrame->vanishingPointWorldSpace, fs.vanishingPointWorldSpace, sizeof fs.vanishingPointWorldSpace);
+			cvx::float3 f = cam.forward();
+			outFrame->forward[0] = f.x; outFrame->forward[1] = f.y; outFrame->forward[2] = f.z;
+			outFrame->totalRays = fs.totalRays;
+		}
+	} catch (const std::exception &e) {
+		return Fail(e.what());
+	}
+	return CVX_OK;
+}
+
+int cvxh_render_manager_read_raybuffer(cvxh_render_manager *rm, int which, int firstRay, int rayCount, uint32_t *dst)
+{
+	if (!rm || !dst) { return Fail("bad argument"); }
+	try {
+		rm->rm->ReadRayBuffer(which, firstRay, rayCount, dst);
+	} catch (const std::exception &e) {
+		return Fail(e.what());
+	}
 	return CVX_OK;
 }
 

@@ -89,6 +89,25 @@ int cvxh_setup_frame(const cvxh_camera_pose *pose, int limitHorizon, float farCl
                      const float LODDistances[CVX_LOD_LEVELS], int screenWidth, int screenHeight,
                      int worldDimensionY, cvxh_frame *out);
 
+/*
+ * RenderManager twin (Assets/Code/RenderManager.cs:12-256): SetResolution :94, SwapBuffers :53, ClearRayBuffer :58,
+ * DrawWorld :111 (vanishing point + segments + CameraData on the host, DrawSegments and BlitSegments on the GPU
+ * through libcpuvox_gpu.so, loaded from gpuLibraryPath).  Fails (no CPU fallback) when the library or a HIP device
+ * is missing.  renderMode: 0 ScreenBuffer, 1 RayBufferTopDown, 2 RayBufferLeftRight (UnityManager.ERenderMode).
+ */
+typedef struct cvxh_render_manager cvxh_render_manager;
+int cvxh_render_manager_create(int device, int screenWidth, int screenHeight, const char *gpuLibraryPath, cvxh_render_manager **out);
+void cvxh_render_manager_destroy(cvxh_render_manager *rm);
+int cvxh_render_manager_upload_world(cvxh_render_manager *rm, const cvxh_world_set *worlds);
+int cvxh_render_manager_set_resolution(cvxh_render_manager *rm, int resolutionX, int resolutionY, int *changed);
+int cvxh_render_manager_swap_buffers(cvxh_render_manager *rm); /* returns the new buffer index */
+int cvxh_render_manager_clear_raybuffer(cvxh_render_manager *rm, int renderMode);
+/* UnityManager.LateUpdate body (UnityManager.cs:179-182): LimitRotationHorizon + DrawWorld.  screenArgb32: W*H
+ * pixels, row 0 = bottom, may be NULL; outFrame (may be NULL) receives the frame setup that was used. */
+int cvxh_render_manager_draw_world(cvxh_render_manager *rm, const cvxh_camera_pose *pose, int limitHorizon, float farClip,
+                                   const float LODDistances[CVX_LOD_LEVELS], uint32_t *screenArgb32, cvxh_frame *outFrame);
+int cvxh_render_manager_read_raybuffer(cvxh_render_manager *rm, int which, int firstRay, int rayCount, uint32_t *dst);
+
 /* BenchmarkPath.anim at clip time t in [0, 1.15], position scaled by world dims (UnityManager.cs:86-87). */
 void cvxh_sample_benchmark_path(float t, const float worldDims[3], float outPosition[3], float outEuler[3]);
 

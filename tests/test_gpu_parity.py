@@ -234,3 +234,41 @@ def test_copy_rows_pack_unpack_round_trip(contexts):
     n_td, n_lr = scenes.used_rows(fr)
     assert (ctx.read_raybuffer(1, 0, 0, n_td) == o_td[:n_td]).all() and (ctx.read_raybuffer(1, 1, 0, n_lr) == o_lr[:n_lr]).all()
     ctx.close()
+
+
+def test_render_manager_twin_draw_world():
+    """The C++ RenderManager twin (SetResolution / SwapBuffers / ClearRayBuffer / DrawWorld) end to end:
+    the screen image equals the Phase-2 rule applied to the ORACLE's raybuffers of the same frame."""
+    from cpuvox_amd import host
+    from cpuvox_amd.render_manager import RAYBUFFER_TOPDOWN, RenderManager
+
+    ws = scenes.load_world("mill256")
+    W, H = 640, 480
+    rm = RenderManager(W, H)
+    rm.upload_world(ws)
+    assert rm.set_resolution(W, H) is False and rm.swap_buffers() == 1 and rm.swap_buffers() == 0
+    for t in (0.0, 0.75, 0.9):
+        pos, eul = host.sample_benchmark_path(t, ws.dims)
+        pose = host.camera_pose(pos, eul, W, H)
+        lods, far = host.setup_lods(pose, ws.max_dimension, W, H)
+        rm.swap_buffers()
+        rm.clear_raybuffer(RAYBUFFER_TOPDOWN)
+        img = rm.draw_world(pose, lods, far)
+        fr = rm.last_frame
+        ref_fr = scenes.make_frame(ws, W, H, pos, eul)
+        assert bytes(fr.camera) == bytes(ref_fr.camera) and [s.RayCount for s in fr.segments] == [s.RayCount for s in ref_fr.segments]
+        o_td, o_lr, _ = O.draw_segments(ws, fr, W, H, clear=0x9314FFFF, counters=False)  # ClearRayBuffer pink: bytes FF FF 14 93
+        n_td, n_lr = scenes.used_rows(fr)
+        assert (rm.read_raybuffer(gpu.RAYBUFFER_TOPDOWN, 0, n_td) == o_td[:n_td]).all()
+        ref = O.blit_reference(fr, o_td, o_lr, W, H, clear=0)
+        assert (img == ref).all(), f"t={t}: {(img != ref).sum()} screen pixels differ"
+    assert rm.set_resolution(320, 240) is True
+    rm.close()
+    with pytest.raises(RuntimeError):
+        import cpuvox_amd.gpu as g
+        old = g.lib_path
+        try:
+            g.lib_path = lambda: "/nonexistent/libcpuvox_gpu.so"
+            RenderManager(W, H)
+        finally:
+            g.lib_path = old
