@@ -165,6 +165,28 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    # ---- N > 1: check, outside the timed region, that the exchanged frames are complete: a frame assembled on its
+    # display rank from N ranks' tiles must equal the same frame rendered whole by that rank alone (GPU vs GPU; the
+    # GPU path itself is pinned to the CPU oracle by tests/).
+    exchange_verified = None
+    if exchange is not None:
+        s_last = total_steps - 1
+        mine = [b for b in range(G) if b % N == rank][:2]
+        assembled = [(ctx.read_raybuffer(b, 0), ctx.read_raybuffer(b, 1)) for b in mine]
+        ctx.set_shard(0, 1)
+        ok = True
+        for (a_td, a_lr), b in zip(assembled, mine):
+            fr = steps_frames[s_last][b]
+            ctx.draw_segments(fr, b)
+            n_td = max(0, fr.segments[0].RayCount) + max(0, fr.segments[1].RayCount)
+            n_lr = max(0, fr.segments[2].RayCount) + max(0, fr.segments[3].RayCount)
+            w_td, w_lr = ctx.read_raybuffer(b, 0), ctx.read_raybuffer(b, 1)
+            ok = ok and bool((a_td[:n_td] == w_td[:n_td]).all() and (a_lr[:n_lr] == w_lr[:n_lr]).all())
+        ctx.set_shard(rank, N)
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        exchange_verified = bool(flag.item())
+
     timed = range(args.warmup, total_steps)
     total_rays = sum(rays_per_step[s] for s in timed)  # whole job: every ray of every frame is rendered by exactly one GPU
     total_frames = G * args.steps
@@ -198,6 +220,7 @@ def main():
             "frames_per_step": G,
             "rays_per_frame_mean": round(total_rays / total_frames, 1),
             "parallelism": f"ray-tile sharding x{N}" + (" + RCCL all_to_all tile exchange" if exchange is not None else ""),
+            "exchange_verified": exchange_verified,
             "world_dims": list(dims),
             "lod_distances": lods,
         },

@@ -272,3 +272,54 @@ def test_render_manager_twin_draw_world():
             RenderManager(W, H)
         finally:
             g.lib_path = old
+
+
+def test_two_rank_exchange_emulated_on_one_gpu():
+    """The multi-GPU path minus RCCL: two contexts render the two shards of every frame, the tile exchange's pack ->
+    (peer-to-peer transfer emulated by a device copy) -> unpack assembles frame f on "rank" f % 2, bit-identical to
+    the oracle.  Exercises cvx_set_shard, cvx_bind_raybuffers, cvx_copy_rows and cpuvox_amd.dist.TileExchange."""
+    import torch
+
+    from cpuvox_amd import dist as cdist
+
+    ws = scenes.load_world("proc256")
+    W, H = 320, 200
+    frames = [scenes.benchmark_frame(ws, W, H, t, 6.0) for t in (0.05, 0.45, 0.75, 0.9)]
+    G, N = len(frames), 2
+    dev = torch.device("cuda", 0)
+    ranks = []
+    for r in range(N):
+        ctx = gpu.Context(0, buffer_count=G)
+        ctx.upload_world(ws)
+        ctx.set_resolution(W, H)
+        ctx.set_shard(r, N)
+        pools = cdist.allocate_pools(G, ctx.raybuffer_layout(0), ctx.raybuffer_layout(1), dev)
+        ctx.bind_raybuffers(pools.td.data_ptr(), pools.td.numel() * 4, pools.lr.data_ptr(), pools.lr.numel() * 4)
+        ex = cdist.TileExchange(frames, W, H, r, N, pools, dev, ctx)
+        cdist.TileExchange.allocate_staging([ex], dev)
+        ctx.draw_segments_batch(frames, 0)
+        ranks.append((ctx, pools, ex))
+    for r in range(N):  # pack on every rank
+        ctx, pools, ex = ranks[r]
+        ex._copy_rows(ex.send_spans, ex._send_spans_dev, ex.send_buf, True)
+    for r in range(N):  # "P2P": rank r's section for peer p lands in p's section for r
+        _, _, ex = ranks[r]
+        for p in range(N):
+            if p == r:
+                continue
+            _, _, exp = ranks[p]
+            s0, s1 = ex.send_off[p], ex.send_off[p + 1]
+            r0, r1 = exp.recv_off[r], exp.recv_off[r + 1]
+            assert s1 - s0 == r1 - r0 > 0
+            exp.recv_buf[r0:r1].copy_(ex.send_buf[s0:s1])
+    torch.cuda.synchronize()
+    for r in range(N):  # unpack, then frame b with b % N == r must be complete on rank r
+        ctx, pools, ex = ranks[r]
+        ex._copy_rows(ex.recv_spans, ex._recv_spans_dev, ex.recv_buf, False)
+        for b, fr in enumerate(frames):
+            if b % N != r:
+                continue
+            o_td, o_lr, _ = O.draw_segments(ws, fr, W, H, clear=0, counters=False)
+            _compare(f"emulated exchange, frame {b} on rank {r}", fr, ctx.read_raybuffer(b, 0), ctx.read_raybuffer(b, 1), o_td, o_lr)
+    for ctx, _, _ in ranks:
+        ctx.close()
