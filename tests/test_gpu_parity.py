@@ -323,3 +323,36 @@ def test_two_rank_exchange_emulated_on_one_gpu():
             _compare(f"emulated exchange, frame {b} on rank {r}", fr, ctx.read_raybuffer(b, 0), ctx.read_raybuffer(b, 1), o_td, o_lr)
     for ctx, _, _ in ranks:
         ctx.close()
+
+
+@pytest.mark.parametrize("case", ["4k_vp_on_screen", "4k_4096_horizontal_lod4"])
+def test_baseline_configs_4_and_5_shapes(case):
+    """BASELINE.json configs 4 / 5 as parity cases (the bench runs config 3): 3840x2160 (120 mask words per lane),
+    VP on screen with 12000 rays; and a 4096-wide world, forward.y = +-0.001 (worst-case precision, single clamped
+    segment), lodError = 4 so that LOD 0-4 are reached.  Bit-exact against the oracle."""
+    from cpuvox_amd import host
+
+    W, H = 3840, 2160
+    if case == "4k_vp_on_screen":
+        ws = scenes.load_world("proc512")
+        frames = [scenes.benchmark_frame(ws, W, H, 0.75, 2.0)]
+        assert abs(frames[0].totalRays - 12000) <= 2
+    else:
+        ws = scenes.load_world("proc4096x512x4096")
+        frames = [scenes.make_frame(ws, W, H, (-0.1 * 4096, 0.5 * 512, -0.1 * 4096), (0.0, 45.0, 0.0), lod_error=4.0),
+                  scenes.make_frame(ws, W, H, (0.4 * 4096, 0.9 * 512, 0.3 * 4096), (0.01, 200.0, 0.0), lod_error=4.0)]
+        assert [abs(f.forward[1]) for f in frames] == pytest.approx([0.001, 0.001], abs=1e-6)
+    ctx = gpu.Context(0)
+    ctx.upload_world(ws)
+    ctx.set_resolution(W, H)
+    for i, fr in enumerate(frames):
+        ctx.enable_counters(True)
+        ctx.clear_raybuffers(0, CLEAR)
+        ctx.draw_segments(fr, 0)
+        o_td, o_lr, cnt = O.draw_segments(ws, fr, W, H, clear=CLEAR)
+        _compare(f"{case}[{i}]", fr, ctx.read_raybuffer(0, 0), ctx.read_raybuffer(0, 1), o_td, o_lr)
+        gc = ctx.counters()
+        assert list(gc.lodVisits) == list(cnt.lodVisits) and gc.P == cnt.P
+        if case != "4k_vp_on_screen" and i == 0:
+            assert sum(1 for v in cnt.lodVisits if v > 0) >= 5, list(cnt.lodVisits)  # LOD 0-4 reached
+    ctx.close()
