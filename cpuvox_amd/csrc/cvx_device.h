@@ -69,6 +69,8 @@ struct DevTile { // one workgroup (= one wave) of the render kernel
 	int32_t seg;
 	int32_t tileInSeg;
 	int32_t pad_;
+	uint32_t *out; // where pixel row 0, lane 0 of this tile lives (pixel y of lane l at out[y*64 + l]); rows outside
+	               // [origMin, origMax] are never touched, so `out` may point in front of the caller's slot
 };
 
 struct DevCounters { // cvx_counters on the device

@@ -77,6 +77,15 @@ struct cvx_context {
 	size_t devFramesCap = 0;
 	DevTile *devTiles = nullptr;
 	size_t devTilesCap = 0;
+	struct UploadSlot {
+		void *pinned = nullptr;
+		size_t bytes = 0;
+		hipEvent_t done = nullptr;
+		bool inFlight = false;
+	};
+	static constexpr int kUploadSlots = 3;
+	UploadSlot upload[kUploadSlots];
+	unsigned uploadNext = 0;
 	std::vector<DevFrame> hostFrames;
 	std::vector<DevTile> hostTiles;
 	std::vector<float> hostTileCost; // estimated DDA steps of the tile's middle ray (launch order: longest first)
@@ -219,8 +228,11 @@ float EstimateTileCost(const cvx_context *ctx, const DevFrame &F, const DevSegme
 
 // Fills SegmentContext[4] the way DrawSegments does (RenderManager.cs:281-318)
 // and appends this frame's tiles.
+// placements: optional caller-chosen output address per tile (canonical order: frame-major, segment-major); 0 = this
+// context does not render the tile.  placeCursor runs over the whole batch.
 int BuildFrame(cvx_context *ctx, const cvx_segment_data segments[4], const cvx_camera_data *camera, int W, int H, const float vp[2],
-               int bufferIndex, int frameIndex, DevFrame &F, std::vector<DevTile> &tiles, LastDraw &last)
+               int bufferIndex, int frameIndex, DevFrame &F, std::vector<DevTile> &tiles, LastDraw &last,
+               const uint64_t *placements, int64_t placementCount, int64_t &placeCursor)
 {
 	if (!Finite(camera->WorldToScreenMatrix, 16) || !Finite(camera->PositionXZ, 2) || !Finite(&camera->PositionY, 1) ||
 	    !Finite(&camera->FarClip, 1) || !Finite(camera->LODDistances, CVX_LOD_LEVELS) || !Finite(vp, 2)) {
@@ -234,10 +246,10 @@ int BuildFrame(cvx_context *ctx, const cvx_segment_data segments[4], const cvx_c
 	for (int i = 0; i < CVX_LOD_LEVELS; i++) { F.lod[i] = camera->LODDistances[i]; }
 	F.inverse = camera->InverseElementIterationDirection ? 1 : 0;
 	F.pad_ = 0;
-	F.poolTD = ctx->poolTD[(size_t)bufferIndex];
-	F.poolLR = ctx->poolLR[(size_t)bufferIndex];
+	F.poolTD = placements ? nullptr : ctx->poolTD[(size_t)bufferIndex];
+	F.poolLR = placements ? nullptr : ctx->poolLR[(size_t)bufferIndex];
 
-	last.valid = true;
+	last.valid = placements == nullptr; // read-back / blit only know the library's own layout
 	last.width = W;
 	last.height = H;
 	last.vp[0] = vp[0];
@@ -286,10 +298,20 @@ int BuildFrame(cvx_context *ctx, const cvx_segment_data segments[4], const cvx_c
 		}
 		const int maskWords = (S.omax >> 5) - (S.omin >> 5) + 1;
 		for (int t = 0; t < segTiles; t++, tileIdInFrame++) {
-			if (tileIdInFrame % ctx->shardCount != ctx->shardIndex) {
-				continue;
+			uint32_t *out;
+			if (placements) {
+				if (placeCursor >= placementCount) {
+					return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "tile placement list shorter than the batch's tile count");
+				}
+				out = reinterpret_cast<uint32_t *>((uintptr_t)placements[placeCursor++]);
+				if (!out) { continue; }
+			} else {
+				if (tileIdInFrame % ctx->shardCount != ctx->shardIndex) {
+					continue;
+				}
+				out = (s < 2 ? F.poolTD : F.poolLR) + ((size_t)(S.tileBase + t) * (size_t)S.colLen) * CVX_WAVE;
 			}
-			tiles.push_back(DevTile{ frameIndex, s, t, 0 });
+			tiles.push_back(DevTile{ frameIndex, s, t, 0, out });
 			ctx->hostTileCost.push_back(EstimateTileCost(ctx, F, S, t));
 			ctx->hostTileWords.push_back(maskWords);
 		}
@@ -362,9 +384,27 @@ int Launch(cvx_context *ctx, int frameCount, int flags)
 	size_t nTiles = ctx->hostTiles.size();
 	int rc = EnsureScratch(ctx, (size_t)frameCount, nTiles);
 	if (rc != CVX_OK) { return rc; }
-	CVX_HIP(ctx, hipMemcpyAsync(ctx->devFrames, ctx->hostFrames.data(), (size_t)frameCount * sizeof(DevFrame), hipMemcpyHostToDevice, ctx->stream));
-	if (nTiles) {
-		CVX_HIP(ctx, hipMemcpyAsync(ctx->devTiles, ctx->hostTiles.data(), nTiles * sizeof(DevTile), hipMemcpyHostToDevice, ctx->stream));
+	// Frame / tile descriptors go through a small ring of pinned staging buffers so that back-to-back asynchronous
+	// draws never read host memory the next call is already overwriting.
+	{
+		cvx_context::UploadSlot &slot = ctx->upload[ctx->uploadNext++ % cvx_context::kUploadSlots];
+		const size_t framesBytes = (size_t)frameCount * sizeof(DevFrame), tilesBytes = nTiles * sizeof(DevTile);
+		if (!slot.done) { CVX_HIP(ctx, hipEventCreateWithFlags(&slot.done, hipEventDisableTiming)); }
+		if (slot.inFlight) { CVX_HIP(ctx, hipEventSynchronize(slot.done)); slot.inFlight = false; }
+		if (slot.bytes < framesBytes + tilesBytes) {
+			if (slot.pinned) { (void)hipHostFree(slot.pinned); slot.pinned = nullptr; slot.bytes = 0; }
+			const size_t want = (framesBytes + tilesBytes) * 3 / 2 + 4096;
+			CVX_HIP(ctx, hipHostMalloc(&slot.pinned, want, hipHostMallocDefault));
+			slot.bytes = want;
+		}
+		std::memcpy(slot.pinned, ctx->hostFrames.data(), framesBytes);
+		if (tilesBytes) { std::memcpy(static_cast<uint8_t *>(slot.pinned) + framesBytes, ctx->hostTiles.data(), tilesBytes); }
+		CVX_HIP(ctx, hipMemcpyAsync(ctx->devFrames, slot.pinned, framesBytes, hipMemcpyHostToDevice, ctx->stream));
+		if (tilesBytes) {
+			CVX_HIP(ctx, hipMemcpyAsync(ctx->devTiles, static_cast<uint8_t *>(slot.pinned) + framesBytes, tilesBytes, hipMemcpyHostToDevice, ctx->stream));
+		}
+		CVX_HIP(ctx, hipEventRecord(slot.done, ctx->stream));
+		slot.inFlight = true;
 	}
 	if (ctx->countersEnabled) {
 		CVX_HIP(ctx, hipMemsetAsync(ctx->devCounters, 0, sizeof(DevCounters), ctx->stream));
@@ -458,6 +498,10 @@ void cvx_destroy(cvx_context *ctx)
 	if (ctx->devCounters) { (void)hipFree(ctx->devCounters); }
 	if (ctx->staging) { (void)hipFree(ctx->staging); }
 	for (hipEvent_t e : ctx->evPairs) { (void)hipEventDestroy(e); }
+	for (auto &slot : ctx->upload) {
+		if (slot.pinned) { (void)hipHostFree(slot.pinned); }
+		if (slot.done) { (void)hipEventDestroy(slot.done); }
+	}
 	if (ctx->bucketReady) { (void)hipEventDestroy(ctx->bucketReady); }
 	for (int b = 0; b < cvx_context::kBuckets; b++) {
 		if (ctx->bucketDone[b]) { (void)hipEventDestroy(ctx->bucketDone[b]); }
@@ -659,31 +703,43 @@ int cvx_set_shard(cvx_context *ctx, int shardIndex, int shardCount)
 	return CVX_OK;
 }
 
-int cvx_draw_segments_batch(cvx_context *ctx, int frameCount, const cvx_segment_data *segments, const cvx_camera_data *cameras,
-                            int screenWidth, int screenHeight, const float *vanishingPoints, int firstBufferIndex, int flags)
+} // extern "C"
+
+namespace {
+// Shared body of cvx_draw_segments_batch (library-owned tile layout) and cvx_draw_segments_placed (caller-chosen
+// output address per tile).
+int DrawBatch(cvx_context *ctx, int frameCount, const cvx_segment_data *segments, const cvx_camera_data *cameras,
+              int screenWidth, int screenHeight, const float *vanishingPoints, int firstBufferIndex,
+              const uint64_t *placements, int64_t placementCount, int flags)
 {
 	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
 	if (frameCount <= 0 || !segments || !cameras || !vanishingPoints) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "bad frame arguments"); }
 	if (ctx->poolTD.empty() || screenWidth != ctx->resX || screenHeight != ctx->resY) {
 		return Fail(ctx, CVX_ERR_NOT_READY, "cvx_set_resolution(%d, %d) has not been called", screenWidth, screenHeight);
 	}
-	if (firstBufferIndex < 0 || firstBufferIndex >= ctx->bufferCount || frameCount > ctx->bufferCount) {
+	if (!placements && (firstBufferIndex < 0 || firstBufferIndex >= ctx->bufferCount || frameCount > ctx->bufferCount)) {
 		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "buffer index %d / %d frames do not fit bufferCount %d", firstBufferIndex, frameCount, ctx->bufferCount);
 	}
 	CVX_HIP(ctx, hipSetDevice(ctx->device));
-	int rc = EnsurePools(ctx);
+	int rc = placements ? CVX_OK : EnsurePools(ctx);
 	if (rc != CVX_OK) { return rc; }
 	rc = SyncWorld(ctx);
 	if (rc != CVX_OK) { return rc; }
+	int64_t placeCursor = 0;
+	LastDraw placedScratch;
 	ctx->hostFrames.assign((size_t)frameCount, DevFrame());
 	ctx->hostTiles.clear();
 	ctx->hostTileCost.clear();
 	ctx->hostTileWords.clear();
 	for (int f = 0; f < frameCount; f++) {
-		int b = (firstBufferIndex + f) % ctx->bufferCount;
+		int b = placements ? 0 : (firstBufferIndex + f) % ctx->bufferCount;
 		rc = BuildFrame(ctx, segments + (size_t)f * 4, cameras + f, screenWidth, screenHeight, vanishingPoints + (size_t)f * 2, b, f,
-		                ctx->hostFrames[(size_t)f], ctx->hostTiles, ctx->last[(size_t)b]);
+		                ctx->hostFrames[(size_t)f], ctx->hostTiles, placements ? placedScratch : ctx->last[(size_t)b],
+		                placements, placementCount, placeCursor);
 		if (rc != CVX_OK) { return rc; }
+	}
+	if (placements && placeCursor != placementCount) {
+		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "tile placement list has %lld entries, the batch has %lld tiles", (long long)placementCount, (long long)placeCursor);
 	}
 	// Bucket tiles by LDS need (<= 8, 17, 34, more mask words per lane); inside a bucket longest tiles first: the
 	// hardware dispatches workgroups in blockIdx order, so the tail of a launch is made of short tiles (LPT).
@@ -705,22 +761,9 @@ int cvx_draw_segments_batch(cvx_context *ctx, int frameCount, const cvx_segment_
 			bucket[i] = (uint8_t)b;
 		}
 		const std::vector<float> &cost = ctx->hostTileCost;
-		static const bool frameMajor = getenv("CVX_ORDER_FRAME_MAJOR") && atoi(getenv("CVX_ORDER_FRAME_MAJOR")) != 0; // experiment
-		if (frameMajor) {
-			// frames with the longest tile first; all tiles of a frame adjacent (longest first inside the frame)
-			std::vector<float> frameCost((size_t)frameCount, 0.f);
-			for (size_t i = 0; i < n; i++) { frameCost[(size_t)ctx->hostTiles[i].frame] = std::max(frameCost[(size_t)ctx->hostTiles[i].frame], cost[i]); }
-			std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-				const int fa = ctx->hostTiles[a].frame, fb = ctx->hostTiles[b].frame;
-				if (bucket[a] != bucket[b]) { return bucket[a] < bucket[b]; }
-				if (fa != fb) { return frameCost[(size_t)fa] != frameCost[(size_t)fb] ? frameCost[(size_t)fa] > frameCost[(size_t)fb] : fa < fb; }
-				return cost[a] > cost[b];
-			});
-		} else {
-			std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-				return bucket[a] != bucket[b] ? bucket[a] < bucket[b] : cost[a] > cost[b];
-			});
-		}
+		std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+			return bucket[a] != bucket[b] ? bucket[a] < bucket[b] : cost[a] > cost[b];
+		});
 		std::vector<DevTile> sorted(n);
 		for (int b = 0; b <= cvx_context::kBuckets; b++) { ctx->bucketBegin[b] = n; }
 		for (int b = 0; b < cvx_context::kBuckets; b++) { ctx->bucketWords[b] = 1; }
@@ -761,6 +804,22 @@ int cvx_draw_segments_batch(cvx_context *ctx, int frameCount, const cvx_segment_
 		ctx->hostTiles.swap(out);
 	}
 	return Launch(ctx, frameCount, flags);
+}
+} // namespace
+
+extern "C" {
+
+int cvx_draw_segments_batch(cvx_context *ctx, int frameCount, const cvx_segment_data *segments, const cvx_camera_data *cameras,
+                            int screenWidth, int screenHeight, const float *vanishingPoints, int firstBufferIndex, int flags)
+{
+	return DrawBatch(ctx, frameCount, segments, cameras, screenWidth, screenHeight, vanishingPoints, firstBufferIndex, nullptr, 0, flags);
+}
+
+int cvx_draw_segments_placed(cvx_context *ctx, int frameCount, const cvx_segment_data *segments, const cvx_camera_data *cameras,
+                             int screenWidth, int screenHeight, const float *vanishingPoints, int64_t tileCount, const uint64_t *tileOut, int flags)
+{
+	if (ctx && !tileOut) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "tileOut is NULL"); }
+	return DrawBatch(ctx, frameCount, segments, cameras, screenWidth, screenHeight, vanishingPoints, 0, tileOut, tileCount, flags);
 }
 
 int cvx_draw_segments(cvx_context *ctx, const cvx_segment_data segments[4], const cvx_camera_data *camera, int screenWidth, int screenHeight,

@@ -817,7 +817,6 @@ __global__ __launch_bounds__(CVX_WAVE, 4) void render_kernel(const DevFrame *__r
 
 	// The mask only covers the words that hold pixels [omin, omax]; `seen` is biased so that the
 	// absolute word index w of a pixel addresses seen[w * 64].
-	const int colLen = S.colLen;
 	const int omin = S.omin, omax = S.omax;
 	const int wordBase = omin >> 5;
 	const int words = (omax >> 5) - wordBase + 1;
@@ -828,8 +827,7 @@ __global__ __launch_bounds__(CVX_WAVE, 4) void render_kernel(const DevFrame *__r
 	// RaySetupJob (:19-39): tile -> (segment, planeRayIndex)
 	const int planeRayIndex = tile.tileInSeg * CVX_WAVE + lane;
 	const bool active = planeRayIndex < S.rayCount;
-	uint32_t *pool = tile.seg < 2 ? F.poolTD : F.poolLR;
-	uint32_t *out = pool + ((size_t)(S.tileBase + tile.tileInSeg) * (size_t)colLen) * CVX_WAVE + lane;
+	uint32_t *out = tile.out + lane;
 	uint32_t *seen = lds + lane - wordBase * CVX_WAVE;
 	ProfLane prof;
 #ifdef CVX_PROFILE_SECTIONS

@@ -175,3 +175,85 @@ class TileExchange:
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
         self._copy_rows(self.recv_spans, getattr(self, "_recv_spans_dev", None), self.recv_buf, False)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Zero-copy sharding: the render kernel writes every tile straight into the buffer it has to end up in
+# (cvx_draw_segments_placed), so the exchange is nothing but one send and one receive per peer.
+# ---------------------------------------------------------------------------------------------------------------
+class ShardPlan:
+    """Placement of one batch of frames on one rank.
+
+    Tile t of frame b (canonical order of libcpuvox_gpu) is rendered by rank t % N and must end up on the frame's
+    display rank b % N.  Per rank and step there are two areas of 256-byte pixel rows:
+      send[dest]      rows of my tiles of frames displayed elsewhere, grouped by destination, in (frame, tile) order;
+      display[owner]  rows of all tiles of the frames I display, grouped by the rank that renders them, in (frame,
+                      tile) order -- the section of owner == me is written by my own kernel, the others arrive by
+                      P2P and are, by construction, exactly the peer's send[me] section.
+    Only rows [origMin, origMax] of a tile exist in either area.
+    """
+
+    def __init__(self, frames, width: int, height: int, rank: int, world_size: int):
+        N = world_size
+        self.rank, self.N = rank, N
+        send_rows = [0] * N
+        disp_rows = [0] * N
+        self.my_tiles = []       # (canonical index, area 0=send/1=display, section, row offset in section, omin)
+        self.display_tiles = {}  # frame b -> list of (kind, tile, seg, owner, row offset in owner's section, omin, rows)
+        index = 0
+        for b, fr in enumerate(frames):
+            if hasattr(fr, "segments"):
+                rc = [s.RayCount for s in fr.segments]
+                ranges = segment_pixel_ranges(fr.vanishingPointScreenSpace, width, height)
+            else:
+                rc, vp = fr
+                ranges = segment_pixel_ranges(vp, width, height)
+            root = b % N
+            for t, (kind, tile, seg) in enumerate(frame_tiles(rc)):
+                owner = t % N
+                lo, hi = ranges[seg]
+                rows = hi - lo + 1
+                if root == rank:
+                    self.display_tiles.setdefault(b, []).append((kind, tile, seg, owner, disp_rows[owner], lo, rows))
+                    if owner == rank:
+                        self.my_tiles.append((index, 1, rank, disp_rows[rank], lo))
+                    disp_rows[owner] += rows
+                elif owner == rank:
+                    self.my_tiles.append((index, 0, root, send_rows[root], lo))
+                    send_rows[root] += rows
+                index += 1
+        self.tile_count = index
+        self.send_start = np.concatenate([[0], np.cumsum(send_rows)]).astype(np.int64)
+        self.disp_start = np.concatenate([[0], np.cumsum(disp_rows)]).astype(np.int64)
+        self.send_total, self.disp_total = int(self.send_start[-1]), int(self.disp_start[-1])
+
+    def tile_out(self, send_ptr: int, disp_ptr: int) -> np.ndarray:
+        """uint64 device address per tile for cvx_draw_segments_placed (0 = not rendered by this rank)."""
+        out = np.zeros(self.tile_count, dtype=np.uint64)
+        base = (send_ptr, disp_ptr)
+        start = (self.send_start, self.disp_start)
+        for index, area, section, off, lo in self.my_tiles:
+            out[index] = base[area] + (int(start[area][section]) + off - lo) * (TILE_RAYS * 4)
+        return out
+
+    def exchange(self, send: torch.Tensor, disp: torch.Tensor):
+        """One isend / irecv per peer on the current stream; returns the requests (wait() orders the stream)."""
+        ops = []
+        for peer in range(self.N):
+            if peer == self.rank:
+                continue
+            s0, s1 = int(self.send_start[peer]), int(self.send_start[peer + 1])
+            r0, r1 = int(self.disp_start[peer]), int(self.disp_start[peer + 1])
+            if s1 > s0:
+                ops.append(dist.P2POp(dist.isend, send[s0:s1], peer))
+            if r1 > r0:
+                ops.append(dist.P2POp(dist.irecv, disp[r0:r1], peer))
+        return dist.batch_isend_irecv(ops) if ops else []
+
+    def display_rows(self, disp: torch.Tensor, frame: int):
+        """(kind, tile, seg, omin, rows tensor [n, 64]) of every tile of a frame this rank displays."""
+        out = []
+        for kind, tile, seg, owner, off, lo, rows in self.display_tiles[frame]:
+            a = int(self.disp_start[owner]) + off
+            out.append((kind, tile, seg, lo, disp[a:a + rows]))
+        return out

@@ -28,7 +28,7 @@ EXPORTS = [
     "cvx_set_buffer_count", "cvx_draw_segments", "cvx_draw_segments_batch", "cvx_set_shard", "cvx_synchronize",
     "cvx_clear_raybuffer", "cvx_read_raybuffer", "cvx_blit_segments", "cvx_raybuffer_device_ptr",
     "cvx_screen_device_ptr", "cvx_last_draw_ms", "cvx_enable_counters", "cvx_get_counters",
-    "cvx_get_raybuffer_layout", "cvx_selftest_math", "cvx_version", "cvx_bind_raybuffers", "cvx_draw_time_stats", "cvx_debug_section_cycles", "cvx_debug_occupancy", "cvx_copy_rows",
+    "cvx_get_raybuffer_layout", "cvx_selftest_math", "cvx_version", "cvx_bind_raybuffers", "cvx_draw_time_stats", "cvx_debug_section_cycles", "cvx_debug_occupancy", "cvx_copy_rows", "cvx_draw_segments_placed",
 ]
 
 
@@ -77,6 +77,7 @@ def lib() -> C.CDLL:
         L.cvx_set_buffer_count.argtypes = [C.c_void_p, C.c_int]
         L.cvx_draw_segments.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
         L.cvx_draw_segments_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
+        L.cvx_draw_segments_placed.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
         L.cvx_set_shard.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.cvx_synchronize.argtypes = [C.c_void_p]
         L.cvx_clear_raybuffer.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint32]
@@ -191,6 +192,13 @@ class Context:
         n, segs, cams, vps = packed
         self._check(lib().cvx_draw_segments_batch(self._h, n, C.addressof(segs), C.addressof(cams), self.width, self.height,
                                                   C.addressof(vps), first_buffer_index, flags))
+
+    def draw_placed(self, packed, tile_out: np.ndarray, flags: int = DRAW_SYNC) -> None:
+        """cvx_draw_segments_placed: packed = pack_batch(frames), tile_out = uint64 device address per tile (0 = skip)."""
+        n, segs, cams, vps = packed
+        tile_out = np.ascontiguousarray(tile_out, dtype=np.uint64)
+        self._check(lib().cvx_draw_segments_placed(self._h, n, C.addressof(segs), C.addressof(cams), self.width, self.height,
+                                                   C.addressof(vps), tile_out.size, tile_out.ctypes.data, flags))
 
     def synchronize(self) -> None:
         self._check(lib().cvx_synchronize(self._h))

@@ -130,6 +130,19 @@ int cvx_draw_segments_batch(cvx_context *ctx, int frameCount, const cvx_segment_
                             const cvx_camera_data *cameras, int screenWidth, int screenHeight,
                             const float *vanishingPoints, int firstBufferIndex, int flags);
 
+/*
+ * Same as cvx_draw_segments_batch, but the caller chooses where every 64-ray tile is written: tileOut[i] is the device
+ * address of pixel row 0 / lane 0 of the i-th tile of the batch (canonical order: frame by frame, segment 0..3, tile
+ * 0.. of the segment = ceil(RayCount / 64) tiles each); pixel y of lane l goes to ((uint32_t*)tileOut[i])[y*64 + l] and
+ * only rows [origMin, origMax] of the tile's segment are ever written, so a slot needs (origMax - origMin + 1) * 256
+ * bytes starting at tileOut[i] + origMin * 256.  tileOut[i] == 0: this context does not render the tile (another GPU
+ * does).  Used by the multi-GPU path to render straight into send / display buffers (cpuvox_amd/dist.py); read-back
+ * and blit do not apply to placed draws.  tileCount must equal the batch's tile count.
+ */
+int cvx_draw_segments_placed(cvx_context *ctx, int frameCount, const cvx_segment_data *segments,
+                             const cvx_camera_data *cameras, int screenWidth, int screenHeight,
+                             const float *vanishingPoints, int64_t tileCount, const uint64_t *tileOut, int flags);
+
 /* Multi-GPU sharding: this context renders only the 64-ray
  * tiles t with t % shardCount == shardIndex.  Default (0, 1) = everything. */
 int cvx_set_shard(cvx_context *ctx, int shardIndex, int shardCount);

@@ -356,3 +356,64 @@ def test_baseline_configs_4_and_5_shapes(case):
         if case != "4k_vp_on_screen" and i == 0:
             assert sum(1 for v in cnt.lodVisits if v > 0) >= 5, list(cnt.lodVisits)  # LOD 0-4 reached
     ctx.close()
+
+
+def _assemble_from_display(plan, disp, frame_index, fr, W, H):
+    """Logical ray-major raybuffers (oracle layout, zeros where nothing is written) from a rank's display area."""
+    td = np.zeros((W + 2 * H, H), dtype=np.uint32)
+    lr = np.zeros((2 * W + H, W), dtype=np.uint32)
+    rc = [max(0, s.RayCount) for s in fr.segments]
+    seg_tile0 = [0, (rc[0] + 63) // 64, 0, (rc[2] + 63) // 64]
+    seg_row0 = [0, rc[0], 0, rc[2]]
+    for kind, tile, seg, lo, rows in plan.display_rows(disp, frame_index):
+        block = rows.cpu().numpy().view(np.uint32)  # [n, 64]: pixel rows lo.., lanes
+        plane0 = (tile - seg_tile0[seg]) * 64
+        lanes = min(64, rc[seg] - plane0)
+        buf = td if kind == 0 else lr
+        buf[seg_row0[seg] + plane0: seg_row0[seg] + plane0 + lanes, lo: lo + block.shape[0]] = block[:, :lanes].T
+    return td, lr
+
+
+def test_zero_copy_sharding_emulated_on_one_gpu():
+    """cvx_draw_segments_placed + cpuvox_amd.dist.ShardPlan: every tile is rendered straight into the send or display
+    buffer it belongs to; "P2P" (emulated: device copy of a peer's send section) completes the frames on their display
+    ranks, bit-identical to the oracle.  Three emulated ranks on one GPU."""
+    import torch
+
+    from cpuvox_amd import dist as cdist
+
+    ws = scenes.load_world("proc256")
+    W, H = 320, 200
+    frames = [scenes.benchmark_frame(ws, W, H, t, 6.0) for t in (0.05, 0.3, 0.45, 0.75, 0.9, 1.1, 0.6)]
+    N = 3
+    dev = torch.device("cuda", 0)
+    ranks = []
+    for r in range(N):
+        ctx = gpu.Context(0)
+        ctx.upload_world(ws)
+        ctx.set_resolution(W, H)
+        plan = cdist.ShardPlan(frames, W, H, r, N)
+        send = torch.zeros((max(1, plan.send_total), 64), dtype=torch.int32, device=dev)
+        disp = torch.zeros((max(1, plan.disp_total), 64), dtype=torch.int32, device=dev)
+        ctx.draw_placed(ctx.pack_batch(frames), plan.tile_out(send.data_ptr(), disp.data_ptr()))
+        ranks.append((ctx, plan, send, disp))
+    # every tile is rendered by exactly one rank
+    assert sum(len(p.my_tiles) for _, p, _, _ in ranks) == ranks[0][1].tile_count
+    for r, (_, plan, send, _) in enumerate(ranks):  # the transfers
+        for p, (_, pplan, _, pdisp) in enumerate(ranks):
+            if p == r:
+                continue
+            s0, s1 = int(plan.send_start[p]), int(plan.send_start[p + 1])
+            r0, r1 = int(pplan.disp_start[r]), int(pplan.disp_start[r + 1])
+            assert s1 - s0 == r1 - r0
+            if s1 > s0:
+                pdisp[r0:r1].copy_(send[s0:s1])
+    torch.cuda.synchronize()
+    for r, (ctx, plan, _, disp) in enumerate(ranks):
+        for b, fr in enumerate(frames):
+            if b % N != r:
+                continue
+            g_td, g_lr = _assemble_from_display(plan, disp, b, fr, W, H)
+            o_td, o_lr, _ = O.draw_segments(ws, fr, W, H, clear=0, counters=False)
+            _compare(f"zero-copy sharding, frame {b} on rank {r}", fr, g_td, g_lr, o_td, o_lr)
+        ctx.close()
