@@ -7,12 +7,17 @@ world with the full LOD chain, camera poses from the reference's built-in benchm
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" = one pass of the hot path over one batch: N*F frames (F = --frames per GPU).  Every
-frame's 64-ray tiles are dealt round-robin to the N GPUs (cvx_set_shard), so each GPU renders F
-frames' worth of rays per step (weak scaling); with N > 1 the rendered tiles are then exchanged
-over RCCL (all_to_all, frame f is assembled on GPU f % N) inside the timed region.
-Rank 0 prints ONE JSON line.  World and camera inputs are synthetic and resident in HBM before the
-timed region; the per-step host->device traffic is the frame parameters (a few KB).
+A "step" = one pass of the hot path over one batch: N*F frames (F = --frames per GPU).
+N = 1: one launch renders the F frames (cvx_draw_segments_batch).
+N > 1: every frame's 64-ray tiles are dealt round-robin to the N GPUs, so each GPU renders F frames' worth of rays
+per step (weak scaling); frame f is displayed on GPU f % N.  The kernel writes every tile straight into the buffer it
+has to end up in (cvx_draw_segments_placed + cpuvox_amd.dist.ShardPlan): tiles of frames displayed elsewhere go into a
+per-destination send section, and the exchange is ONE send and ONE receive per peer (grouped ncclSend/ncclRecv on
+RCCL, each pair on its own xGMI link), overlapped with the next step's render on a second stream.  The exchange is
+inside the timed region; afterwards frames assembled from N ranks' tiles are compared with the same frames rendered
+whole by their display rank.
+Rank 0 prints ONE JSON line.  World and camera inputs are synthetic and resident in HBM before the timed region; the
+per-step host->device traffic is the frame / tile descriptors (a few hundred KB).
 """
 from __future__ import annotations
 
@@ -40,8 +45,11 @@ def parse_args():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--world", default="proc2048", help="proc<dim> | mill512 | mill256")
     ap.add_argument("--lod-error", type=float, default=1.0)
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall time of the cpu_baseline sample at N = 1 (0 = skip)")
     ap.add_argument("--no-exchange", action="store_true", help="N > 1: skip the RCCL tile exchange (replica-style throughput)")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: finish each step's exchange before the next render")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' = single-GPU rehearsal of the N > 1 path "
+                    "(all ranks share the visible GPUs, tiles travel through host memory)")
     return ap.parse_args()
 
 
@@ -76,6 +84,7 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
         args.gpus = world_size
 
+    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -83,11 +92,15 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    local_rank %= torch.cuda.device_count()  # only differs from LOCAL_RANK in a --backend gloo rehearsal
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     N = args.gpus
     if N > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(args.backend)
 
     def barrier():
         if N > 1:
@@ -109,94 +122,135 @@ def main():
         return host.setup_frame(host.camera_pose(pos, eul, W, H), lods, far, W, H, dims[1])
 
     steps_frames = [[frame_for(s * G + i) for i in range(G)] for s in range(total_steps)]
+    rays_per_step = [sum(f.totalRays for f in frames) for frames in steps_frames]
 
     # ---- device context -----------------------------------------------------------------------------
-    ctx = gpu.Context(local_rank, buffer_count=G)
+    sharded = N > 1
+    ctx = gpu.Context(local_rank, buffer_count=1 if sharded else G)
     ctx.upload_world(ws)
     ctx.set_resolution(W, H)
-    ctx.set_shard(rank, N)
-    exchange = None
-    if N > 1 and not args.no_exchange:
+    packed = [ctx.pack_batch(frames) for frames in steps_frames]
+
+    plans = tile_outs = None
+    send = disp = None
+    s_render = s_exchange = None
+    if sharded:
         from cpuvox_amd import dist as cdist
 
-        lay_td, lay_lr = ctx.raybuffer_layout(0), ctx.raybuffer_layout(1)
-        pools = cdist.allocate_pools(G, lay_td, lay_lr, device)
-        ctx.bind_raybuffers(pools.td.data_ptr(), pools.td.numel() * 4, pools.lr.data_ptr(), pools.lr.numel() * 4)
-        exchange = [cdist.TileExchange(frames, W, H, rank, N, pools, device, ctx) for frames in steps_frames]
-        cdist.TileExchange.allocate_staging(exchange, device)
-    packed = [ctx.pack_batch(frames) for frames in steps_frames]
-    rays_per_step = [sum(f.totalRays for f in frames) for frames in steps_frames]
+        plans = [cdist.ShardPlan(frames, W, H, rank, N) for frames in steps_frames]
+        send_rows = max(1, max(p.send_total for p in plans))
+        disp_rows = max(1, max(p.disp_total for p in plans))
+        # two parities: step s+1 renders into the other pair while step s is still on the wire
+        send = [torch.zeros((send_rows, cdist.TILE_RAYS), dtype=torch.int32, device=device) for _ in range(2)]
+        disp = [torch.zeros((disp_rows, cdist.TILE_RAYS), dtype=torch.int32, device=device) for _ in range(2)]
+        tile_outs = [plans[s].tile_out(send[s % 2].data_ptr(), disp[s % 2].data_ptr()) for s in range(total_steps)]
+        s_render, s_exchange = torch.cuda.Stream(device), torch.cuda.Stream(device)
+        ctx.set_stream(s_render.cuda_stream)
+
+    def draw(s: int, flags: int):
+        if sharded:
+            ctx.draw_placed(packed[s], tile_outs[s], flags)
+        else:
+            ctx.draw_packed(packed[s], 0, flags)
 
     # ---- algorithmic bytes per launch: instrumented pass, outside the timed region -------------------
     ctx.enable_counters(True)
-    alg_bytes = []
-    visits = []
+    alg_bytes, visits = [], []
     for s in range(total_steps):
-        ctx.draw_packed(packed[s], 0, gpu.DRAW_SYNC)
+        draw(s, gpu.DRAW_SYNC)
         c = ctx.counters()
         alg_bytes.append(c.algorithmic_bytes())
         visits.append(c.S)
     ctx.enable_counters(False)
 
-    def run_step(s: int):
-        ctx.draw_packed(packed[s], 0, gpu.DRAW_ASYNC)
-        if exchange is not None:
-            # the render stream belongs to the context, the exchange runs on torch's stream: order them on the host
-            ctx.synchronize()
-            exchange[s].run()
-            torch.cuda.synchronize()
+    def run_region(first: int, last: int, overlap: bool):
+        """Steps [first, last): render (+ exchange).  Returns after everything has completed on this rank."""
+        ev_done = {}
+        for s in range(first, last):
+            if not sharded or args.no_exchange:
+                draw(s, gpu.DRAW_ASYNC)
+                continue
+            par = s % 2
+            if s - 2 in ev_done:
+                s_render.wait_event(ev_done[s - 2])  # the exchange that read / filled this parity has finished
+            draw(s, gpu.DRAW_ASYNC)                   # enqueued on s_render (the context's stream)
+            ev_render = torch.cuda.Event()
+            ev_render.record(s_render)
+            s_exchange.wait_event(ev_render)
+            with torch.cuda.stream(s_exchange):
+                for req in plans[s].exchange(send[par], disp[par]):
+                    req.wait()
+                ev_done[s] = torch.cuda.Event()
+                ev_done[s].record(s_exchange)
+            if not overlap:
+                ev_done[s].synchronize()
+        ctx.synchronize()
+        torch.cuda.synchronize()
 
-    for s in range(args.warmup):
-        run_step(s)
-    ctx.synchronize()
-    torch.cuda.synchronize()
-    barrier()
-
-    ctx.draw_time_stats(reset=True)
-    t0 = time.perf_counter()
-    for s in range(args.warmup, total_steps):
-        run_step(s)
-    ctx.synchronize()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if N > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-
-    # ---- N > 1: check, outside the timed region, that the exchanged frames are complete: a frame assembled on its
-    # display rank from N ranks' tiles must equal the same frame rendered whole by that rank alone (GPU vs GPU; the
-    # GPU path itself is pinned to the CPU oracle by tests/).
-    exchange_verified = None
-    if exchange is not None:
-        s_last = total_steps - 1
-        mine = [b for b in range(G) if b % N == rank][:2]
-        assembled = [(ctx.read_raybuffer(b, 0), ctx.read_raybuffer(b, 1)) for b in mine]
-        ctx.set_shard(0, 1)
+    def verify_exchange(step: int) -> bool:
+        """Frames assembled on this rank from N ranks' tiles == the same frames rendered whole here (GPU vs GPU;
+        the GPU path itself is pinned to the CPU oracle by tests/)."""
         ok = True
-        for (a_td, a_lr), b in zip(assembled, mine):
-            fr = steps_frames[s_last][b]
-            ctx.draw_segments(fr, b)
-            n_td = max(0, fr.segments[0].RayCount) + max(0, fr.segments[1].RayCount)
-            n_lr = max(0, fr.segments[2].RayCount) + max(0, fr.segments[3].RayCount)
-            w_td, w_lr = ctx.read_raybuffer(b, 0), ctx.read_raybuffer(b, 1)
-            ok = ok and bool((a_td[:n_td] == w_td[:n_td]).all() and (a_lr[:n_lr] == w_lr[:n_lr]).all())
-        ctx.set_shard(rank, N)
-        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+        mine = [b for b in range(G) if b % N == rank][:2]
+        for b in mine:
+            fr = steps_frames[step][b]
+            rc = [s.RayCount for s in fr.segments]
+            a_td, a_lr = plans[step].assemble(disp[step % 2], b, rc, W, H)
+            ctx.clear_raybuffers(0, 0)
+            ctx.draw_segments(fr, 0)
+            n_td, n_lr = max(0, rc[0]) + max(0, rc[1]), max(0, rc[2]) + max(0, rc[3])
+            w_td = ctx.read_raybuffer(0, gpu.RAYBUFFER_TOPDOWN, 0, n_td)
+            w_lr = ctx.read_raybuffer(0, gpu.RAYBUFFER_LEFTRIGHT, 0, n_lr)
+            ok = ok and bool((a_td[:n_td] == w_td).all() and (a_lr[:n_lr] == w_lr).all())
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        exchange_verified = bool(flag.item())
+        return bool(flag.item())
 
-    timed = range(args.warmup, total_steps)
-    total_rays = sum(rays_per_step[s] for s in timed)  # whole job: every ray of every frame is rendered by exactly one GPU
+    def timed(overlap: bool):
+        run_region(0, args.warmup, overlap)
+        barrier()
+        ctx.draw_time_stats(reset=True)
+        t0 = time.perf_counter()
+        run_region(args.warmup, total_steps, overlap)
+        barrier()
+        dt = time.perf_counter() - t0
+        if N > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt
+
+    overlap = sharded and not args.no_exchange and not args.no_overlap
+    elapsed = timed(overlap)
+    k_ms_total, k_draws = ctx.draw_time_stats(reset=True)  # HIP events around each launch, on the launch stream
+    exchange_verified = None
+    if sharded and not args.no_exchange:
+        exchange_verified = verify_exchange(total_steps - 1)
+        if not exchange_verified and overlap:
+            # never report a number from a run whose frames are wrong: redo the region without overlap
+            overlap = False
+            elapsed = timed(False)
+            k_ms_total, k_draws = ctx.draw_time_stats(reset=True)
+            exchange_verified = verify_exchange(total_steps - 1)
+
+    steps = range(args.warmup, total_steps)
+    total_rays = sum(rays_per_step[s] for s in steps)  # whole job: every ray of every frame is rendered by exactly one GPU
     total_frames = G * args.steps
     value = total_rays / elapsed / 1e6
     # roofline of the dominant kernel (render_kernel) on this rank: algorithmic bytes of its launches / their duration
-    k_bytes = sum(alg_bytes[s] for s in timed)
-    k_ms_total, k_draws = ctx.draw_time_stats(reset=True)  # HIP events around each launch, on the launch stream
-    kernel_ms = [k_ms_total / max(1, k_draws)] * max(1, k_draws)
+    k_bytes = sum(alg_bytes[s] for s in steps)
     k_sec = k_ms_total / 1e3
     achieved = k_bytes / k_sec / 1e9
+    if sharded and not args.no_exchange:
+        parallelism = f"ray-tile sharding x{N}, zero-copy placement + RCCL P2P tile exchange" + (" overlapped with the next render" if overlap else "")
+    else:
+        parallelism = f"ray-tile sharding x{N}" + (" (no exchange)" if sharded else "")
+
+    if args.world.startswith("proc"):
+        workload = (f"procedural {args.world} world seed 0x5EED2048, {W}x{H}, full LOD chain (6 levels), benchmark-path poses "
+                    f"({POSES} samples, stride {POSE_STRIDE}), lodError {args.lod_error}")
+    else:
+        workload = f"{args.world} (mill.obj voxelised), {W}x{H}, benchmark-path poses, lodError {args.lod_error}"
 
     result = {
         "metric": "Mrays/s, Phase-1 raybuffer rendering (DrawSegmentRayJob) at 1080p, 2048^3 world",
@@ -213,14 +267,13 @@ def main():
         "data": "synthetic",
         "fps": round(total_frames / elapsed, 2),
         "config": {
-            "workload": f"procedural {args.world} world seed 0x5EED2048, {W}x{H}, full LOD chain (6 levels), benchmark-path poses "
-                        f"({POSES} samples, stride {POSE_STRIDE}), lodError {args.lod_error}" if args.world.startswith("proc") else
-                        f"{args.world} (mill.obj voxelised), {W}x{H}, benchmark-path poses, lodError {args.lod_error}",
+            "workload": workload,
             "frames_per_gpu_per_step": F,
             "frames_per_step": G,
             "rays_per_frame_mean": round(total_rays / total_frames, 1),
-            "parallelism": f"ray-tile sharding x{N}" + (" + RCCL all_to_all tile exchange" if exchange is not None else ""),
+            "parallelism": parallelism,
             "exchange_verified": exchange_verified,
+            "exchange_bytes_per_step_per_gpu": int(np.mean([p.send_total for p in plans]) * 256) if sharded else 0,
             "world_dims": list(dims),
             "lod_distances": lods,
         },
@@ -232,10 +285,10 @@ def main():
             "frac": round(achieved / HBM_PEAK_GBS, 5),
             "traffic": None,
             "kernel": "cvxk::render_kernel",
-            "kernel_ms_avg": round(sum(kernel_ms) / len(kernel_ms), 4),
-            "algorithmic_bytes_per_launch": int(k_bytes / len(kernel_ms)),
+            "kernel_ms_avg": round(k_ms_total / max(1, k_draws), 4),
+            "algorithmic_bytes_per_launch": int(k_bytes / max(1, k_draws)),
             "bytes_per_ray": round(k_bytes / max(1, total_rays / N), 1),
-            "column_visits_per_s": round(sum(visits[s] for s in timed) / k_sec, 1),
+            "column_visits_per_s": round(sum(visits[s] for s in steps) / k_sec, 1),
         },
     }
 
@@ -254,18 +307,13 @@ def cpu_baseline(ws, frames, W, H, budget_s: float):
     RenderJob) timed on this box's host cores on a bounded sample of the same frames.  kind = "port":
     the reference itself (C#/Unity/Burst) cannot run here."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oraclelib as O
-
     import numpy as np
+    import oraclelib as O
 
     threads = O.lib().orc_max_threads()
     (td_rays, td_w), (lr_rays, lr_w) = O.raybuffer_shapes(W, H)
     bufs = (np.zeros((td_rays, td_w), dtype=np.uint32), np.zeros((lr_rays, lr_w), dtype=np.uint32))
     O.draw_segments(ws, frames[0], W, H, counters=False, out=bufs)  # warm-up (page in the world)
-    t0 = time.perf_counter()
-    O.draw_segments(ws, frames[0], W, H, counters=False, out=bufs)
-    per_frame = max(1e-4, time.perf_counter() - t0)
-    del per_frame
     rays = 0
     n = 0
     t0 = time.perf_counter()

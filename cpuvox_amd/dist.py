@@ -233,22 +233,57 @@ class ShardPlan:
         base = (send_ptr, disp_ptr)
         start = (self.send_start, self.disp_start)
         for index, area, section, off, lo in self.my_tiles:
-            out[index] = base[area] + (int(start[area][section]) + off - lo) * (TILE_RAYS * 4)
+            out[index] = (base[area] + (int(start[area][section]) + off - lo) * (TILE_RAYS * 4)) & 0xFFFFFFFFFFFFFFFF
         return out
 
     def exchange(self, send: torch.Tensor, disp: torch.Tensor):
-        """One isend / irecv per peer on the current stream; returns the requests (wait() orders the stream)."""
+        """One isend / irecv per peer on the current stream; returns the requests (wait() orders the stream).
+        With the gloo backend and device tensors (single-GPU rehearsals of the multi-GPU path) the transfer is staged
+        through host memory and has completed on return."""
+        via_host = send.is_cuda and dist.get_backend() == "gloo"
+        if via_host:
+            torch.cuda.current_stream().synchronize()
         ops = []
+        received = []
         for peer in range(self.N):
             if peer == self.rank:
                 continue
             s0, s1 = int(self.send_start[peer]), int(self.send_start[peer + 1])
             r0, r1 = int(self.disp_start[peer]), int(self.disp_start[peer + 1])
             if s1 > s0:
-                ops.append(dist.P2POp(dist.isend, send[s0:s1], peer))
+                ops.append(dist.P2POp(dist.isend, send[s0:s1].cpu() if via_host else send[s0:s1], peer))
             if r1 > r0:
-                ops.append(dist.P2POp(dist.irecv, disp[r0:r1], peer))
-        return dist.batch_isend_irecv(ops) if ops else []
+                if via_host:
+                    buf = torch.empty((r1 - r0, TILE_RAYS), dtype=disp.dtype)
+                    received.append((r0, r1, buf))
+                    ops.append(dist.P2POp(dist.irecv, buf, peer))
+                else:
+                    ops.append(dist.P2POp(dist.irecv, disp[r0:r1], peer))
+        reqs = dist.batch_isend_irecv(ops) if ops else []
+        if via_host:
+            for req in reqs:
+                req.wait()
+            for r0, r1, buf in received:
+                disp[r0:r1].copy_(buf)
+            torch.cuda.current_stream().synchronize()
+            return []
+        return reqs
+
+    def assemble(self, disp: torch.Tensor, frame: int, ray_counts, width: int, height: int):
+        """Logical ray-major raybuffers (the reference layout, RayBuffer.cs:121-128; zeros where nothing is written)
+        of a frame this rank displays -- for verification / read-back, on the host."""
+        td = np.zeros((width + 2 * height, height), dtype=np.uint32)
+        lr = np.zeros((2 * width + height, width), dtype=np.uint32)
+        rc = [max(0, int(c)) for c in ray_counts]
+        seg_tile0 = [0, (rc[0] + TILE_RAYS - 1) // TILE_RAYS, 0, (rc[2] + TILE_RAYS - 1) // TILE_RAYS]
+        seg_row0 = [0, rc[0], 0, rc[2]]
+        for kind, tile, seg, lo, rows in self.display_rows(disp, frame):
+            block = rows.cpu().numpy().view(np.uint32)
+            plane0 = (tile - seg_tile0[seg]) * TILE_RAYS
+            lanes = min(TILE_RAYS, rc[seg] - plane0)
+            buf = td if kind == 0 else lr
+            buf[seg_row0[seg] + plane0: seg_row0[seg] + plane0 + lanes, lo: lo + block.shape[0]] = block[:, :lanes].T
+        return td, lr
 
     def display_rows(self, disp: torch.Tensor, frame: int):
         """(kind, tile, seg, omin, rows tensor [n, 64]) of every tile of a frame this rank displays."""

@@ -110,3 +110,71 @@ def test_frame_tiles_matches_the_library_numbering():
     assert [s for _, _, s in tiles] == [0, 0, 0, 1, 3, 3]
     assert cdist.frame_tiles([0, 0, 0, 0]) == []
     assert cdist.tile_capacity(1920, 1080) == ((1920 + 2160 + 63) // 64 + 2, (3840 + 1080 + 63) // 64 + 2)
+
+
+def _tile_rows(frame, td, lr, kind, tile, seg, lo, rows):
+    """What the kernel writes for one tile: pixel rows [lo, lo+rows) x 64 lanes, from the oracle's ray-major buffers."""
+    rc = [max(0, s.RayCount) for s in frame.segments]
+    seg_tile0 = [0, (rc[0] + 63) // 64, 0, (rc[2] + 63) // 64]
+    seg_row0 = [0, rc[0], 0, rc[2]]
+    plane0 = (tile - seg_tile0[seg]) * 64
+    lanes = min(64, rc[seg] - plane0)
+    out = np.zeros((rows, 64), dtype=np.uint32)
+    buf = td if kind == 0 else lr
+    out[:, :lanes] = buf[seg_row0[seg] + plane0: seg_row0[seg] + plane0 + lanes, lo: lo + rows].T
+    return out
+
+
+def _shard_worker(rank, world_size, port, result_queue):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        ws = scenes.load_world("proc256")
+        frames = [scenes.benchmark_frame(ws, W, H, t, 6.0) for t in TIMES]
+        plan = cdist.ShardPlan(frames, W, H, rank, world_size)
+        send = torch.zeros((max(1, plan.send_total), 64), dtype=torch.int32)
+        disp = torch.zeros((max(1, plan.disp_total), 64), dtype=torch.int32)
+        oracle = [O.draw_segments(ws, fr, W, H, threads=2)[:2] for fr in frames]
+        # "render": put my tiles where ShardPlan.tile_out tells the kernel to put them
+        out = plan.tile_out(1 << 40, 1 << 41)  # fake bases (the address may lie in front of the slot: rows < origMin)
+        index = 0
+        areas = (send.numpy().view(np.uint32), disp.numpy().view(np.uint32))
+        for b, fr in enumerate(frames):
+            ranges = cdist.segment_pixel_ranges(fr.vanishingPointScreenSpace, W, H)
+            for kind, tile, seg in cdist.frame_tiles([s.RayCount for s in fr.segments]):
+                addr = int(out[index])
+                index += 1
+                if addr == 0:
+                    continue
+                lo, hi = ranges[seg]
+                area = 1 if addr >= (3 << 39) else 0
+                row = (addr - ((1 << 41) if area else (1 << 40))) // 256 + lo  # tile_out points at pixel row 0
+                areas[area][row: row + hi - lo + 1] = _tile_rows(fr, oracle[b][0], oracle[b][1], kind, tile, seg, lo, hi - lo + 1)
+        for req in plan.exchange(send, disp):
+            req.wait()
+        ok = True
+        for b, fr in enumerate(frames):
+            if b % world_size != rank:
+                continue
+            td, lr = plan.assemble(disp, b, [s.RayCount for s in fr.segments], W, H)
+            n_td, n_lr = scenes.used_rows(fr)
+            ok = ok and bool((td[:n_td] == oracle[b][0][:n_td]).all() and (lr[:n_lr] == oracle[b][1][:n_lr]).all())
+        result_queue.put((rank, ok, plan.send_total, plan.disp_total))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_zero_copy_shard_plan_world_size_2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _, _ in results), results
+    assert results[0][2] > 0 and results[1][2] > 0

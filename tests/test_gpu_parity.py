@@ -358,22 +358,6 @@ def test_baseline_configs_4_and_5_shapes(case):
     ctx.close()
 
 
-def _assemble_from_display(plan, disp, frame_index, fr, W, H):
-    """Logical ray-major raybuffers (oracle layout, zeros where nothing is written) from a rank's display area."""
-    td = np.zeros((W + 2 * H, H), dtype=np.uint32)
-    lr = np.zeros((2 * W + H, W), dtype=np.uint32)
-    rc = [max(0, s.RayCount) for s in fr.segments]
-    seg_tile0 = [0, (rc[0] + 63) // 64, 0, (rc[2] + 63) // 64]
-    seg_row0 = [0, rc[0], 0, rc[2]]
-    for kind, tile, seg, lo, rows in plan.display_rows(disp, frame_index):
-        block = rows.cpu().numpy().view(np.uint32)  # [n, 64]: pixel rows lo.., lanes
-        plane0 = (tile - seg_tile0[seg]) * 64
-        lanes = min(64, rc[seg] - plane0)
-        buf = td if kind == 0 else lr
-        buf[seg_row0[seg] + plane0: seg_row0[seg] + plane0 + lanes, lo: lo + block.shape[0]] = block[:, :lanes].T
-    return td, lr
-
-
 def test_zero_copy_sharding_emulated_on_one_gpu():
     """cvx_draw_segments_placed + cpuvox_amd.dist.ShardPlan: every tile is rendered straight into the send or display
     buffer it belongs to; "P2P" (emulated: device copy of a peer's send section) completes the frames on their display
@@ -413,7 +397,7 @@ def test_zero_copy_sharding_emulated_on_one_gpu():
         for b, fr in enumerate(frames):
             if b % N != r:
                 continue
-            g_td, g_lr = _assemble_from_display(plan, disp, b, fr, W, H)
+            g_td, g_lr = plan.assemble(disp, b, [s.RayCount for s in fr.segments], W, H)
             o_td, o_lr, _ = O.draw_segments(ws, fr, W, H, clear=0, counters=False)
             _compare(f"zero-copy sharding, frame {b} on rank {r}", fr, g_td, g_lr, o_td, o_lr)
         ctx.close()
