@@ -272,15 +272,25 @@ __device__ __forceinline__ void reduce_pixel_horizon(const uint32_t *seen, int o
 // shares).  Reported per section: max over the lanes of a wave (~ wave time in the section), summed over waves, and
 // the lane sum (lane-cycles; / (64 * wave time) = lane utilisation).
 #ifdef CVX_PROFILE_SECTIONS
-#define CVX_NSEC 9
+#define CVX_NSEC 16
 __device__ unsigned long long g_sectionCycles[32]; // [n] wave cycles, [16+n] lane cycles / 64
 struct ProfLane {
 	unsigned int last;
 	unsigned int acc[CVX_NSEC];
 };
+#ifdef CVX_PROFILE_COUNTS
+// counting variant: [n] = number of times a wave executed the code at CVX_COUNT(n) (exactly one lane of the executing
+// wave increments), no time stamps
+#define CVX_COUNT(n) do { if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) { prof.acc[n]++; } } while (0)
+#define CVX_BEGIN() ((void)0)
+#define CVX_END(n) ((void)0)
+#else
+#define CVX_COUNT(n) ((void)0)
 #define CVX_BEGIN() (prof.last = (unsigned int)__builtin_amdgcn_s_memtime())
 #define CVX_END(n) do { const unsigned int t_ = (unsigned int)__builtin_amdgcn_s_memtime(); prof.acc[n] += t_ - prof.last; prof.last = t_; } while (0)
+#endif
 #else
+#define CVX_COUNT(n) ((void)0)
 struct ProfLane {};
 #define CVX_BEGIN() ((void)0)
 #define CVX_END(n) ((void)0)
@@ -399,7 +409,9 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		const f3 camSpaceMaxLast = f3_madd(planeStartTop, planeDir, curDistLast);
 		const f3 camSpaceMaxNext = f3_madd(planeStartTop, planeDir, curDistNext);
 
+		CVX_COUNT(8);
 		if (curDistLast > 2.0f && frustumDirMaxWorld == CVX_FLOAT_EPSILON) { // :295-422
+			CVX_COUNT(2);
 			float clipLastMinLerp, clipLastMaxLerp, clipNextMinLerp, clipNextMaxLerp;
 			const bool clippedLast = clip_world_bounds(camSpaceMinLast, camSpaceMaxLast, frustumBoundsMin, frustumBoundsMax, clipLastMinLerp, clipLastMaxLerp);
 			const bool clippedNext = clip_world_bounds(camSpaceMinNext, camSpaceMaxNext, frustumBoundsMin, frustumBoundsMax, clipNextMinLerp, clipNextMaxLerp);
@@ -511,6 +523,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			bool found = false;
 			CVX_BEGIN();
 			while (true) {
+				CVX_COUNT(3);
 				elementPointer += DIR;
 				uint32_t raw;
 				if (queued == 0 && extPending) {
@@ -564,6 +577,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			f3 camSpaceFrontTop = f3_lerp(camSpaceMinLast, camSpaceMaxLast, portionTop);
 
 			// side of the run, :484-542
+			CVX_COUNT(4);
 			{
 				float uA = (float)elementLength;
 				float uB = 0.0f;
@@ -582,6 +596,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 					uB = m_lerp(uA, uB, v);
 				}
 				if (visible) {
+					CVX_COUNT(9);
 					float uvAx = 1.0f / camSpaceFrontBottom.z, uvAy = uA / camSpaceFrontBottom.z;
 					float uvBx = 1.0f / camSpaceFrontTop.z, uvBy = uB / camSpaceFrontTop.z;
 					float boundsX = camSpaceFrontBottom.x / camSpaceFrontBottom.z; // ProjectClippedToScreen, CameraData.cs:160
@@ -594,6 +609,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 					int rbMin = f2i(rintf(boundsX));
 					int rbMax = f2i(rintf(boundsY));
 					if (rbMax >= nextFreePixelMin && rbMin <= nextFreePixelMax) {
+						CVX_COUNT(10);
 						reduce_pixel_horizon(seen, omin, omax, rbMin, rbMax, nextFreePixelMin, nextFreePixelMax, frustumBoundsMin, frustumBoundsMax);
 						CVX_END(4);
 						for (int w = rbMin >> 5; w <= (rbMax >> 5); w++) { // pixel loop :519-533 over unseen bits
@@ -604,6 +620,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 								seen[w * CVX_WAVE] = m | range;
 								frustumDirMaxWorld = CVX_FLOAT_EPSILON;
 								do {
+									CVX_COUNT(5);
 									const int y = (w << 5) + (__ffs((int)todo) - 1);
 									todo &= todo - 1u;
 									float l = ((float)y - boundsX) / (boundsY - boundsX); // unlerp
@@ -648,6 +665,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 				continue;
 			}
 
+			CVX_COUNT(6);
 			bool visible = true; // ClipHomogeneousCameraSpaceLine, CameraData.cs:124-138
 			if (secA.y <= 0.0f) {
 				if (secB.y <= 0.0f) {
@@ -661,6 +679,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 				secB = f3_lerp(secA, secB, v);
 			}
 			if (visible) {
+				CVX_COUNT(11);
 				float bx = rintf(secA.x / secA.z);
 				float by = rintf(secB.x / secB.z);
 				int rbMin = f2i(bx);
@@ -669,6 +688,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 					int t = rbMin; rbMin = rbMax; rbMax = t;
 				}
 				if (rbMax >= nextFreePixelMin && rbMin <= nextFreePixelMax) {
+					CVX_COUNT(12);
 					reduce_pixel_horizon(seen, omin, omax, rbMin, rbMax, nextFreePixelMin, nextFreePixelMax, frustumBoundsMin, frustumBoundsMax);
 					CVX_END(6);
 					for (int w = rbMin >> 5; w <= (rbMax >> 5); w++) { // :595-603
@@ -679,6 +699,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 							seen[w * CVX_WAVE] = m | range;
 							frustumDirMaxWorld = CVX_FLOAT_EPSILON;
 							do {
+								CVX_COUNT(7);
 								const int y = (w << 5) + (__ffs((int)todo) - 1);
 								todo &= todo - 1u;
 								out[y * CVX_WAVE] = secondaryColor;
@@ -724,6 +745,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 
 	while (true) {
 		CVX_BEGIN();
+		CVX_COUNT(1);
 		if (--guardSteps <= 0) {
 			return;
 		}
@@ -870,6 +892,11 @@ __global__ __launch_bounds__(CVX_WAVE, 4) void render_kernel(const DevFrame *__r
 #ifdef CVX_PROFILE_SECTIONS
 	CVX_END(8);
 	for (int i = 0; i < CVX_NSEC; i++) {
+#ifdef CVX_PROFILE_COUNTS
+		unsigned int tot = prof.acc[i];
+		for (int o = 32; o > 0; o >>= 1) { tot += (unsigned int)__shfl_xor((int)tot, o); }
+		if (lane == 0) { atomicAdd(&g_sectionCycles[i], (unsigned long long)tot); }
+#else
 		unsigned int mx = prof.acc[i], sum = prof.acc[i] >> 6;
 		for (int o = 32; o > 0; o >>= 1) {
 			mx = max(mx, (unsigned int)__shfl_xor((int)mx, o));
@@ -879,6 +906,7 @@ __global__ __launch_bounds__(CVX_WAVE, 4) void render_kernel(const DevFrame *__r
 			atomicAdd(&g_sectionCycles[i], (unsigned long long)mx);
 			atomicAdd(&g_sectionCycles[16 + i], (unsigned long long)sum);
 		}
+#endif
 	}
 #endif
 	if (COUNT) {
