@@ -40,7 +40,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step (kept in flight in one launch)")
+    ap.add_argument("--frames", type=int, default=512, help="frames per GPU per step (kept in flight in one launch)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--world", default="proc2048", help="proc<dim> | mill512 | mill256")

@@ -626,7 +626,7 @@ int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byt
 int cvx_set_buffer_count(cvx_context *ctx, int bufferCount)
 {
 	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
-	if (bufferCount < 1 || bufferCount > 256) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "bufferCount must be in [1, 256]"); }
+	if (bufferCount < 1 || bufferCount > 4096) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "bufferCount must be in [1, 4096]"); }
 	if (bufferCount != ctx->bufferCount) {
 		CVX_HIP(ctx, hipSetDevice(ctx->device));
 		CVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
