@@ -90,15 +90,7 @@ struct cvx_context {
 	std::vector<DevTile> hostTiles;
 	std::vector<float> hostTileCost; // estimated DDA steps of the tile's middle ray (launch order: longest first)
 	std::vector<int> hostTileWords;  // LDS mask words per lane the tile needs
-	// The kernel is latency bound: throughput scales with resident waves, and LDS (the per-lane seen mask) is
-	// what limits them.  LDS size is fixed per launch, so tiles are bucketed by mask size and every bucket is
-	// launched with exactly the LDS it needs, on its own stream, concurrently.
-	static constexpr int kBuckets = 4;
-	hipStream_t bucketStream[kBuckets] = {};
-	hipEvent_t bucketReady = nullptr;
-	hipEvent_t bucketDone[kBuckets] = {};
-	size_t bucketBegin[kBuckets + 1] = {};
-	int bucketWords[kBuckets] = {};
+	int maskWordsNeeded = 1;         // LDS mask words per lane the current launch needs (widest [origMin, origMax] window)
 
 	int shardIndex = 0, shardCount = 1;
 	bool countersEnabled = false;
@@ -414,27 +406,18 @@ int Launch(cvx_context *ctx, int frameCount, int flags)
 	if (rc != CVX_OK) { return rc; }
 	CVX_HIP(ctx, hipEventRecord(evStart, ctx->stream));
 	if (nTiles) {
-		// The iteration direction (RenderJob.Execute :174-178) is a wave-uniform runtime switch inside the kernel,
-		// so one launch per LDS bucket covers all frames of the batch; the buckets run concurrently.
-		static const size_t ldsPad = getenv("CVX_LDS_PAD") ? (size_t)atoi(getenv("CVX_LDS_PAD")) : 0; // occupancy experiments only
-		CVX_HIP(ctx, hipEventRecord(ctx->bucketReady, ctx->stream));
-		for (int b = 0; b < cvx_context::kBuckets; b++) {
-			const size_t begin = ctx->bucketBegin[b], end = ctx->bucketBegin[b + 1];
-			if (end <= begin) { continue; }
-			hipStream_t st = ctx->bucketStream[b];
-			CVX_HIP(ctx, hipStreamWaitEvent(st, ctx->bucketReady, 0));
-			const size_t ldsBytes = (size_t)ctx->bucketWords[b] * CVX_WAVE * sizeof(uint32_t) + ldsPad;
-			dim3 grid((unsigned)(end - begin)), block(CVX_WAVE);
-			const DevTile *tiles = ctx->devTiles + begin;
-			if (ctx->countersEnabled) {
-				hipLaunchKernelGGL((cvxk::render_kernel<true>), grid, block, ldsBytes, st, ctx->devFrames, tiles, ctx->devWorld, ctx->devCounters);
-			} else {
-				hipLaunchKernelGGL((cvxk::render_kernel<false>), grid, block, ldsBytes, st, ctx->devFrames, tiles, ctx->devWorld, ctx->devCounters);
-			}
-			CVX_HIP(ctx, hipGetLastError());
-			CVX_HIP(ctx, hipEventRecord(ctx->bucketDone[b], st));
-			CVX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->bucketDone[b], 0));
+		// One launch for the whole batch: the iteration direction (RenderJob.Execute :174-178) is a wave-uniform
+		// runtime switch inside the kernel, so the tails of different frames overlap.  LDS = the widest seen-mask any
+		// tile of the batch needs.  (Splitting the batch into concurrent launches by LDS need was measured and lost:
+		// launches that share a hardware queue serialise, and more than ~10 resident waves per CU add nothing.)
+		const size_t ldsBytes = (size_t)ctx->maskWordsNeeded * CVX_WAVE * sizeof(uint32_t);
+		dim3 grid((unsigned)nTiles), block(CVX_WAVE);
+		if (ctx->countersEnabled) {
+			hipLaunchKernelGGL((cvxk::render_kernel<true>), grid, block, ldsBytes, ctx->stream, ctx->devFrames, ctx->devTiles, ctx->devWorld, ctx->devCounters);
+		} else {
+			hipLaunchKernelGGL((cvxk::render_kernel<false>), grid, block, ldsBytes, ctx->stream, ctx->devFrames, ctx->devTiles, ctx->devWorld, ctx->devCounters);
 		}
+		CVX_HIP(ctx, hipGetLastError());
 	}
 	CVX_HIP(ctx, hipEventRecord(evStop, ctx->stream));
 	if (!(flags & CVX_DRAW_ASYNC)) {
@@ -473,11 +456,6 @@ int cvx_create(int device, cvx_context **out)
 	if ((e = hipStreamCreateWithFlags(&ctx->ownStream, hipStreamNonBlocking)) != hipSuccess) { return bail(e, "hipStreamCreate"); }
 	ctx->stream = ctx->ownStream;
 	if ((e = hipMalloc((void **)&ctx->devCounters, sizeof(DevCounters))) != hipSuccess) { return bail(e, "hipMalloc"); }
-	if ((e = hipEventCreateWithFlags(&ctx->bucketReady, hipEventDisableTiming)) != hipSuccess) { return bail(e, "hipEventCreate"); }
-	for (int b = 0; b < cvx_context::kBuckets; b++) {
-		if ((e = hipStreamCreateWithFlags(&ctx->bucketStream[b], hipStreamNonBlocking)) != hipSuccess) { return bail(e, "hipStreamCreate"); }
-		if ((e = hipEventCreateWithFlags(&ctx->bucketDone[b], hipEventDisableTiming)) != hipSuccess) { return bail(e, "hipEventCreate"); }
-	}
 	*out = ctx;
 	return CVX_OK;
 }
@@ -501,11 +479,6 @@ void cvx_destroy(cvx_context *ctx)
 	for (auto &slot : ctx->upload) {
 		if (slot.pinned) { (void)hipHostFree(slot.pinned); }
 		if (slot.done) { (void)hipEventDestroy(slot.done); }
-	}
-	if (ctx->bucketReady) { (void)hipEventDestroy(ctx->bucketReady); }
-	for (int b = 0; b < cvx_context::kBuckets; b++) {
-		if (ctx->bucketDone[b]) { (void)hipEventDestroy(ctx->bucketDone[b]); }
-		if (ctx->bucketStream[b]) { (void)hipStreamDestroy(ctx->bucketStream[b]); }
 	}
 	if (ctx->ownStream) { (void)hipStreamDestroy(ctx->ownStream); }
 	delete ctx;
@@ -741,67 +714,21 @@ int DrawBatch(cvx_context *ctx, int frameCount, const cvx_segment_data *segments
 	if (placements && placeCursor != placementCount) {
 		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "tile placement list has %lld entries, the batch has %lld tiles", (long long)placementCount, (long long)placeCursor);
 	}
-	// Bucket tiles by LDS need (<= 8, 17, 34, more mask words per lane); inside a bucket longest tiles first: the
-	// hardware dispatches workgroups in blockIdx order, so the tail of a launch is made of short tiles (LPT).
+	// Longest tiles first: the hardware dispatches workgroups in blockIdx order, so the tail of the launch is made of
+	// short tiles (LPT scheduling).  XCD-affine and frame-major orders were measured and were no better / worse.
 	{
-		// Measured on MI355X: the runtime serialises launches that share a hardware queue and resident waves
-		// beyond ~10 per CU no longer add throughput, so by default everything goes into ONE bucket (one launch,
-		// one tail).  CVX_LDS_BUCKETS=1 restores the 4-way split for experiments.
-		static const bool split = getenv("CVX_LDS_BUCKETS") && atoi(getenv("CVX_LDS_BUCKETS")) != 0;
-		static const int kLimitSplit[cvx_context::kBuckets] = { 8, 17, 34, 1 << 30 };
-		static const int kLimitOne[cvx_context::kBuckets] = { 1 << 30, 1 << 30, 1 << 30, 1 << 30 };
-		const int *kLimit = split ? kLimitSplit : kLimitOne;
 		const size_t n = ctx->hostTiles.size();
 		std::vector<uint32_t> order(n);
-		std::vector<uint8_t> bucket(n);
+		ctx->maskWordsNeeded = 1;
 		for (size_t i = 0; i < n; i++) {
 			order[i] = (uint32_t)i;
-			int b = 0;
-			while (ctx->hostTileWords[i] > kLimit[b]) { b++; }
-			bucket[i] = (uint8_t)b;
+			if (ctx->hostTileWords[i] > ctx->maskWordsNeeded) { ctx->maskWordsNeeded = ctx->hostTileWords[i]; }
 		}
 		const std::vector<float> &cost = ctx->hostTileCost;
-		std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-			return bucket[a] != bucket[b] ? bucket[a] < bucket[b] : cost[a] > cost[b];
-		});
+		std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
 		std::vector<DevTile> sorted(n);
-		for (int b = 0; b <= cvx_context::kBuckets; b++) { ctx->bucketBegin[b] = n; }
-		for (int b = 0; b < cvx_context::kBuckets; b++) { ctx->bucketWords[b] = 1; }
-		for (size_t i = 0; i < n; i++) {
-			const uint32_t src = order[i];
-			sorted[i] = ctx->hostTiles[src];
-			const int b = bucket[src];
-			if (i < ctx->bucketBegin[b]) { ctx->bucketBegin[b] = i; }
-			if (ctx->hostTileWords[src] > ctx->bucketWords[b]) { ctx->bucketWords[b] = ctx->hostTileWords[src]; }
-		}
-		for (int b = cvx_context::kBuckets - 1; b >= 0; b--) { // empty buckets start where the next one starts
-			if (ctx->bucketBegin[b] > ctx->bucketBegin[b + 1]) { ctx->bucketBegin[b] = ctx->bucketBegin[b + 1]; }
-		}
+		for (size_t i = 0; i < n; i++) { sorted[i] = ctx->hostTiles[order[i]]; }
 		ctx->hostTiles.swap(sorted);
-	}
-	// XCD affinity: workgroup b is observed to run on XCD b % 8 (MI355X_MICROARCH.md, dispatch round-robin; speed
-	// only, never correctness).  Keep all tiles of a frame on one XCD so that the columns near the camera, which
-	// many of the frame's rays visit, are served by that XCD's L2.  Slot i*8+k holds the i-th tile (LPT order) of
-	// the frames with f % 8 == k; when a list runs out the remaining slots are filled from the others.
-	static const bool xcdAffinity = !(getenv("CVX_XCD_AFFINITY") && atoi(getenv("CVX_XCD_AFFINITY")) == 0);
-	if (xcdAffinity && frameCount >= 8 && ctx->bucketBegin[1] == ctx->hostTiles.size()) {
-		const size_t n = ctx->hostTiles.size();
-		std::vector<DevTile> lists[8];
-		for (const DevTile &t : ctx->hostTiles) { lists[t.frame & 7].push_back(t); }
-		std::vector<DevTile> out;
-		out.reserve(n);
-		size_t cursor[8] = {};
-		std::vector<DevTile> leftovers;
-		size_t minLen = n;
-		for (int k = 0; k < 8; k++) { if (lists[k].size() < minLen) { minLen = lists[k].size(); } }
-		for (size_t i = 0; i < minLen; i++) {
-			for (int k = 0; k < 8; k++) { out.push_back(lists[k][cursor[k]++]); }
-		}
-		for (int k = 0; k < 8; k++) {
-			while (cursor[k] < lists[k].size()) { leftovers.push_back(lists[k][cursor[k]++]); }
-		}
-		out.insert(out.end(), leftovers.begin(), leftovers.end());
-		ctx->hostTiles.swap(out);
 	}
 	return Launch(ctx, frameCount, flags);
 }
