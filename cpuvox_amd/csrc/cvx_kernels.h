@@ -33,7 +33,10 @@ __device__ __forceinline__ int m_clampi(int x, int a, int b) { return max(a, min
 // INT_MIN.  v_cvt_i32_f32 saturates instead, so the rule is explicit.
 __device__ __forceinline__ int f2i(float x)
 {
-	return (x != x || x >= 2147483648.0f || x < -2147483648.0f) ? (int)0x80000000 : (int)x;
+	// v_cvt_i32_f32 truncates, saturates and maps NaN to 0: only NaN and x >= 2^31 differ from the x86 rule
+	int r;
+	asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+	return (x < 2147483648.0f) ? r : (int)0x80000000;
 }
 
 struct f3 {
