@@ -761,27 +761,23 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		curExt = nextExt;
 		const int curLod = lod;
 		const bool lastColumn = dda_step(ray, farClip); // true: far clip reached after this column
-		bool nextOutside = false;
-		uint4 nextHeader = { 0u, 0u, 0u, 0u }, nextQueue = { 0u, 0u, 0u, 0u };
-		if (!lastColumn) {
-			if (ray.distLast >= lodMax && lod < 5) {
-				dda_next_lod(ray, voxelScale);
-				lod++;
-				voxelScale *= 2;
-				L = world->level[lod];
-				table = DIR > 0 ? L.columnsDown : L.columnsUp;
-				extTable = DIR > 0 ? L.extDown : L.extUp;
-				lodMax = F.lod[lod];
-			}
-			nextOutside = (ray.px & maskX) != ray.px || (ray.pz & maskZ) != ray.pz;
-			if (!nextOutside) {
-				const size_t column = (size_t)((ray.px >> L.shift) * L.mulX + (ray.pz >> L.shift));
-				const uint4 *rec = table + 2 * column;
-				nextHeader = rec[0];
-				nextQueue = rec[1];
-				nextExt = extTable + column;
-			}
+		// (the LOD check and the fetch are done for every lane, also one that stops after this column: its state is
+		// dead, and an unconditional, in-bounds load is cheaper than branching around it)
+		if (ray.distLast >= lodMax && lod < 5) {
+			dda_next_lod(ray, voxelScale);
+			lod++;
+			voxelScale *= 2;
+			L = world->level[lod];
+			table = DIR > 0 ? L.columnsDown : L.columnsUp;
+			extTable = DIR > 0 ? L.extDown : L.extUp;
+			lodMax = F.lod[lod];
 		}
+		const bool nextOutside = (ray.px & maskX) != ray.px || (ray.pz & maskZ) != ray.pz;
+		const size_t column = (size_t)(((ray.px & maskX) >> L.shift) * L.mulX + ((ray.pz & maskZ) >> L.shift)); // clamped into the table
+		const uint4 *rec = table + 2 * column;
+		const uint4 nextHeader = rec[0];
+		const uint4 nextQueue = rec[1];
+		nextExt = extTable + column;
 
 		// ---- the current column, exactly as the reference processes it
 		if (COUNT) {
