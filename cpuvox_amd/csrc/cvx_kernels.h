@@ -135,16 +135,14 @@ __device__ __forceinline__ bool dda_step_to_world_intersection(DDA &d, float dim
 
 __device__ __forceinline__ bool dda_step(DDA &d, float farClip) // :135-150
 {
-	float crossed;
-	if (d.tMaxX < d.tMaxZ) {
-		crossed = d.tMaxX;
-		d.tMaxX += d.tDeltaX;
-		d.px += d.sx;
-	} else {
-		crossed = d.tMaxZ;
-		d.tMaxZ += d.tDeltaZ;
-		d.pz += d.sz;
-	}
+	// branch-free form of "if (tMax.x < tMax.y) step x else step z" (same values, no exec-mask juggling)
+	const bool stepX = d.tMaxX < d.tMaxZ;
+	const float crossed = stepX ? d.tMaxX : d.tMaxZ;
+	const float nextX = d.tMaxX + d.tDeltaX, nextZ = d.tMaxZ + d.tDeltaZ;
+	d.tMaxX = stepX ? nextX : d.tMaxX;
+	d.tMaxZ = stepX ? d.tMaxZ : nextZ;
+	d.px += stepX ? d.sx : 0;
+	d.pz += stepX ? 0 : d.sz;
 	d.distLast = crossed;
 	d.distNext = m_min(d.tMaxX, d.tMaxZ);
 	return crossed >= farClip;
