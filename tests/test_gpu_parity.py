@@ -104,6 +104,22 @@ def test_random_poses_fuzz(contexts):
         _compare(f"fuzz{i} pos={pos} eul={eul}", fr, g_td, g_lr, o_td, o_lr)
 
 
+def test_random_poses_fuzz_mill_and_odd_resolutions(contexts):
+    """Sparse model world (empty columns, StepToWorldIntersection from outside) at non-multiple-of-32/64 resolutions."""
+    rng = np.random.default_rng(7731)
+    ws = scenes.load_world("mill256")
+    for W, H in ((333, 217), (640, 360), (97, 401)):
+        ctx = contexts("mill256", W, H)
+        for i in range(12):
+            frac = rng.uniform(-0.5, 1.5, size=3)
+            pos = [frac[k] * ws.dims[k] for k in range(3)]
+            eul = [rng.uniform(-89, 89), rng.uniform(0, 360), rng.choice([0.0, rng.uniform(0, 360)])]
+            fr = scenes.make_frame(ws, W, H, pos, eul)
+            g_td, g_lr = _render_gpu(ctx, fr)
+            o_td, o_lr, _ = O.draw_segments(ws, fr, W, H, clear=CLEAR, counters=False)
+            _compare(f"millfuzz {W}x{H} #{i} pos={pos} eul={eul}", fr, g_td, g_lr, o_td, o_lr)
+
+
 def test_batch_equals_single_frames(contexts):
     """cvx_draw_segments_batch (many frames per launch, mixed iteration directions) == frame-by-frame draws."""
     ws = scenes.load_world("proc256")
