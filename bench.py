@@ -155,12 +155,13 @@ def main():
 
     # ---- algorithmic bytes per launch: instrumented pass, outside the timed region -------------------
     ctx.enable_counters(True)
-    alg_bytes, visits = [], []
+    alg_bytes, visits, lod_visits = [], [], []
     for s in range(total_steps):
         draw(s, gpu.DRAW_SYNC)
         c = ctx.counters()
         alg_bytes.append(c.algorithmic_bytes())
         visits.append(c.S)
+        lod_visits.append(list(c.lodVisits))
     ctx.enable_counters(False)
 
     def run_region(first: int, last: int, overlap: bool):
@@ -276,6 +277,7 @@ def main():
             "exchange_bytes_per_step_per_gpu": int(np.mean([p.send_total for p in plans]) * 256) if sharded else 0,
             "world_dims": list(dims),
             "lod_distances": lods,
+            "lod_visits_per_step": [int(np.mean([lod_visits[s][l] for s in steps])) for l in range(6)],
         },
         "roofline": {
             "bound": "hbm",

@@ -164,35 +164,24 @@ __device__ __forceinline__ float clip_max(f3 pMin, f3 pMax, float frustum) // :1
 	return c1 / (c1 - c0);
 }
 
-// GetWorldBoundsClippingCamSpace, :51-99.  true = entirely outside.
+// GetWorldBoundsClippingCamSpace, :51-99.  true = entirely outside (the lerps are then unused by the caller).
+// Flattened form of the reference's if-tree: with a1/a2 = pMin/pMax above fMax and b1/b2 = pMin/pMax below fMin the tree
+// evaluates at most one "min" clip (against fMax when a1, else against fMin when b1) and at most one "max" clip (against
+// fMax when a2 and not a1, else against fMin when b2); the arithmetic of each is the tree's own, so the values are the
+// same, but divergent lanes of a wave now share one instance of each division sequence instead of six.
 __device__ __forceinline__ bool clip_world_bounds(f3 pMin, f3 pMax, float fMin, float fMax, float &minLerp, float &maxLerp)
 {
-	minLerp = 0.0f;
-	maxLerp = 1.0f;
-	if (pMin.x > pMin.z * fMax) {
-		if (pMax.x > pMax.z * fMax) {
-			return true;
-		}
-		minLerp = clip_min(pMin, pMax, fMax);
-		if (pMax.x < pMax.z * fMin) {
-			maxLerp = clip_max(pMin, pMax, fMin);
-		}
-	} else if (pMax.x > pMax.z * fMax) {
-		maxLerp = clip_max(pMin, pMax, fMax);
-		if (pMin.x < pMin.z * fMin) {
-			minLerp = clip_min(pMin, pMax, fMin);
-		}
-	} else {
-		if (pMin.x < pMin.z * fMin) {
-			if (pMax.x < pMax.z * fMin) {
-				return true;
-			}
-			minLerp = clip_min(pMin, pMax, fMin);
-		} else if (pMax.x < pMax.z * fMin) {
-			maxLerp = clip_max(pMin, pMax, fMin);
-		}
-	}
-	return false;
+	const bool a1 = pMin.x > pMin.z * fMax;
+	const bool a2 = pMax.x > pMax.z * fMax;
+	const bool b1 = pMin.x < pMin.z * fMin;
+	const bool b2 = pMax.x < pMax.z * fMin;
+	const bool needMin = a1 || b1;
+	const bool needMax = a1 ? b2 : (a2 || b2);
+	const float lo = clip_min(pMin, pMax, a1 ? fMax : fMin);
+	const float hi = clip_max(pMin, pMax, (!a1 && a2) ? fMax : fMin);
+	minLerp = needMin ? lo : 0.0f;
+	maxLerp = needMax ? hi : 1.0f;
+	return a1 ? a2 : (!a2 && b1 && b2);
 }
 
 // ---- seen-pixel bitmask in LDS ---------------------------------------------
@@ -278,11 +267,14 @@ __device__ unsigned long long g_sectionCycles[32]; // [n] wave cycles, [16+n] la
 struct ProfLane {
 	unsigned int last;
 	unsigned int acc[CVX_NSEC];
+#ifdef CVX_PROFILE_COUNTS
+	unsigned int lanes[CVX_NSEC]; // how often THIS lane was active at CVX_COUNT(n); summed over lanes -> [16 + n]
+#endif
 };
 #ifdef CVX_PROFILE_COUNTS
 // counting variant: [n] = number of times a wave executed the code at CVX_COUNT(n) (exactly one lane of the executing
 // wave increments), no time stamps
-#define CVX_COUNT(n) do { if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) { prof.acc[n]++; } } while (0)
+#define CVX_COUNT(n) do { prof.lanes[n]++; if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) { prof.acc[n]++; } } while (0)
 #define CVX_BEGIN() ((void)0)
 #define CVX_END(n) ((void)0)
 #else
@@ -417,62 +409,29 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			const bool clippedLast = clip_world_bounds(camSpaceMinLast, camSpaceMaxLast, frustumBoundsMin, frustumBoundsMax, clipLastMinLerp, clipLastMaxLerp);
 			const bool clippedNext = clip_world_bounds(camSpaceMinNext, camSpaceMaxNext, frustumBoundsMin, frustumBoundsMax, clipNextMinLerp, clipNextMaxLerp);
 
-			float camSpaceClippedMin, camSpaceClippedMax;
-			if (clippedLast) {
-				if (clippedNext) {
-					return false;
-				}
-				worldBoundsMin = m_lerp(0.0f, worldMaxY, clipNextMinLerp);
-				worldBoundsMax = m_lerp(0.0f, worldMaxY, clipNextMaxLerp);
-				frustumDirMaxWorld = (worldBoundsMax - posY) / curDistNext;
-				frustumDirMinWorld = (worldBoundsMin - posY) / curDistNext;
-				f3 minClip = f3_lerp(camSpaceMinNext, camSpaceMaxNext, clipNextMinLerp);
-				f3 maxClip = f3_lerp(camSpaceMinNext, camSpaceMaxNext, clipNextMaxLerp);
-				camSpaceClippedMin = minClip.x / minClip.z;
-				camSpaceClippedMax = maxClip.x / maxClip.z;
-				if (camSpaceClippedMax < camSpaceClippedMin) {
-					float t = camSpaceClippedMin; camSpaceClippedMin = camSpaceClippedMax; camSpaceClippedMax = t;
-				}
-			} else if (clippedNext) {
-				worldBoundsMin = m_lerp(0.0f, worldMaxY, clipLastMinLerp);
-				worldBoundsMax = m_lerp(0.0f, worldMaxY, clipLastMaxLerp);
-				f3 minClip = f3_lerp(camSpaceMinLast, camSpaceMaxLast, clipLastMinLerp);
-				f3 maxClip = f3_lerp(camSpaceMinLast, camSpaceMaxLast, clipLastMaxLerp);
-				frustumDirMaxWorld = (worldBoundsMax - posY) / curDistLast;
-				frustumDirMinWorld = (worldBoundsMin - posY) / curDistLast;
-				camSpaceClippedMin = minClip.x / minClip.z;
-				camSpaceClippedMax = maxClip.x / maxClip.z;
-				if (camSpaceClippedMax < camSpaceClippedMin) {
-					float t = camSpaceClippedMin; camSpaceClippedMin = camSpaceClippedMax; camSpaceClippedMax = t;
-				}
-			} else {
-				if (clipLastMinLerp < clipNextMinLerp) {
-					worldBoundsMin = m_lerp(0.0f, worldMaxY, clipLastMinLerp);
-					frustumDirMinWorld = (worldBoundsMin - posY) / curDistLast;
-				} else {
-					worldBoundsMin = m_lerp(0.0f, worldMaxY, clipNextMinLerp);
-					frustumDirMinWorld = (worldBoundsMin - posY) / curDistNext;
-				}
-				if (clipLastMaxLerp > clipNextMaxLerp) {
-					worldBoundsMax = m_lerp(0.0f, worldMaxY, clipLastMaxLerp);
-					frustumDirMaxWorld = (worldBoundsMax - posY) / curDistLast;
-				} else {
-					worldBoundsMax = m_lerp(0.0f, worldMaxY, clipNextMaxLerp);
-					frustumDirMaxWorld = (worldBoundsMax - posY) / curDistNext;
-				}
-				f3 minClipA = f3_lerp(camSpaceMinLast, camSpaceMaxLast, clipLastMinLerp);
-				f3 maxClipA = f3_lerp(camSpaceMinLast, camSpaceMaxLast, clipLastMaxLerp);
-				f3 minClipB = f3_lerp(camSpaceMinNext, camSpaceMaxNext, clipNextMinLerp);
-				f3 maxClipB = f3_lerp(camSpaceMinNext, camSpaceMaxNext, clipNextMaxLerp);
-				float minNext = minClipB.x / minClipB.z;
-				float minLast = minClipA.x / minClipA.z;
-				float maxNext = maxClipB.x / maxClipB.z;
-				float maxLast = maxClipA.x / maxClipA.z;
-				if (maxNext < minNext) { float t = maxNext; maxNext = minNext; minNext = t; }
-				if (maxLast < minLast) { float t = maxLast; maxLast = minLast; minLast = t; }
-				camSpaceClippedMin = m_min(minLast, minNext);
-				camSpaceClippedMax = m_max(maxLast, maxNext);
+			if (clippedLast && clippedNext) {
+				return false;
 			}
+			// :300-390, the three cases (only Next visible / only Last visible / both) folded into selects: each
+			// bound comes from the Last or the Next intersection, chosen exactly as the reference's branches do.
+			const bool minFromLast = !clippedLast && (clippedNext || clipLastMinLerp < clipNextMinLerp);
+			const bool maxFromLast = !clippedLast && (clippedNext || clipLastMaxLerp > clipNextMaxLerp);
+			worldBoundsMin = m_lerp(0.0f, worldMaxY, minFromLast ? clipLastMinLerp : clipNextMinLerp);
+			worldBoundsMax = m_lerp(0.0f, worldMaxY, maxFromLast ? clipLastMaxLerp : clipNextMaxLerp);
+			frustumDirMinWorld = (worldBoundsMin - posY) / (minFromLast ? curDistLast : curDistNext);
+			frustumDirMaxWorld = (worldBoundsMax - posY) / (maxFromLast ? curDistLast : curDistNext);
+			const f3 minClipA = f3_lerp(camSpaceMinLast, camSpaceMaxLast, clipLastMinLerp);
+			const f3 maxClipA = f3_lerp(camSpaceMinLast, camSpaceMaxLast, clipLastMaxLerp);
+			const f3 minClipB = f3_lerp(camSpaceMinNext, camSpaceMaxNext, clipNextMinLerp);
+			const f3 maxClipB = f3_lerp(camSpaceMinNext, camSpaceMaxNext, clipNextMaxLerp);
+			float minNext = minClipB.x / minClipB.z;
+			float minLast = minClipA.x / minClipA.z;
+			float maxNext = maxClipB.x / maxClipB.z;
+			float maxLast = maxClipA.x / maxClipA.z;
+			if (maxNext < minNext) { float t = maxNext; maxNext = minNext; minNext = t; }
+			if (maxLast < minLast) { float t = maxLast; maxLast = minLast; minLast = t; }
+			const float camSpaceClippedMin = clippedLast ? minNext : (clippedNext ? minLast : m_min(minLast, minNext));
+			const float camSpaceClippedMax = clippedLast ? maxNext : (clippedNext ? maxLast : m_max(maxLast, maxNext));
 
 			worldBoundsMin = floorf(worldBoundsMin);
 			worldBoundsMax = ceilf(worldBoundsMax);
@@ -851,6 +810,9 @@ __global__ __launch_bounds__(CVX_WAVE, 4) void render_kernel(const DevFrame *__r
 	ProfLane prof;
 #ifdef CVX_PROFILE_SECTIONS
 	for (int i = 0; i < CVX_NSEC; i++) { prof.acc[i] = 0u; }
+#ifdef CVX_PROFILE_COUNTS
+	for (int i = 0; i < CVX_NSEC; i++) { prof.lanes[i] = 0u; }
+#endif
 	CVX_BEGIN();
 #endif
 
@@ -890,9 +852,9 @@ __global__ __launch_bounds__(CVX_WAVE, 4) void render_kernel(const DevFrame *__r
 	CVX_END(8);
 	for (int i = 0; i < CVX_NSEC; i++) {
 #ifdef CVX_PROFILE_COUNTS
-		unsigned int tot = prof.acc[i];
-		for (int o = 32; o > 0; o >>= 1) { tot += (unsigned int)__shfl_xor((int)tot, o); }
-		if (lane == 0) { atomicAdd(&g_sectionCycles[i], (unsigned long long)tot); }
+		unsigned long long tot = prof.acc[i], act = prof.lanes[i];
+		for (int o = 32; o > 0; o >>= 1) { tot += (unsigned long long)__shfl_xor((long long)tot, o); act += (unsigned long long)__shfl_xor((long long)act, o); }
+		if (lane == 0) { atomicAdd(&g_sectionCycles[i], tot); atomicAdd(&g_sectionCycles[16 + i], act); }
 #else
 		unsigned int mx = prof.acc[i], sum = prof.acc[i] >> 6;
 		for (int o = 32; o > 0; o >>= 1) {

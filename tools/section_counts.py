@@ -29,4 +29,4 @@ c = ctx.counters()
 cyc = ctx.debug_section_cycles()
 print(f"{frames_n} frames: lane-level S={c.S} E={c.E} C={c.C} P={c.P} R={c.R}")
 for k in (1, 8, 2, 3, 4, 9, 10, 5, 6, 11, 12, 7):
-    print(f"{NAMES[k]:40s} {cyc[k]:12d}  per wave-step {cyc[k] / max(1, cyc[1]):6.3f}")
+    print(f"{NAMES[k]:40s} {cyc[k]:12d}  per wave-step {cyc[k] / max(1, cyc[1]):6.3f}   active lanes per execution {cyc[16 + k] / max(1, cyc[k]):5.1f}")
