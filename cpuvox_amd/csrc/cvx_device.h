@@ -1,11 +1,11 @@
 // cvx_device.h -- device-side data layout of libcpuvox_gpu (gfx950 only).
 //
-// World: per LOD a dense array of 16-byte column headers (x-major, index
-// (x>>lod)*(dimZ>>lod) + (z>>lod) like World.GetIndexKnownInBounds,
-// World.cs:145-149) plus the element pool in the reference's own order
-// [guard][run 0..n-1][guard][colour 0..s-1] (World.cs:163-165).  The 12-byte
-// reference header (World.cs:161-169) is widened to 16 bytes on upload so a
-// header is one aligned dwordx4 load.
+// World: per LOD and per walk direction a dense array of 32-byte column
+// records (x-major, index (x>>lod)*(dimZ>>lod) + (z>>lod) like
+// World.GetIndexKnownInBounds, World.cs:145-149) built on upload from the
+// reference's 12-byte headers (World.cs:161-169), plus the element pool in the
+// reference's own order [guard][run 0..n-1][guard][colour 0..s-1]
+// (World.cs:163-165), from which the kernel reads the colours.
 //
 // Raybuffer: tile-major.  A tile is 64 consecutive rays of one segment (one
 // wavefront); inside a tile pixel y of lane l lives at (y*64 + l), so a wave
@@ -21,16 +21,21 @@
 #define CVX_SKYBOX_ARGB 0x191919FFu /* ColorARGB32(25,25,25): bytes FF 19 19 19 (DrawSegmentRayJob.cs:702) */
 
 struct DevWorldLevel {
-	// 32-byte column records, one table per element iteration direction:
-	//   [0] = {elemOffset, runCount | worldMin << 16, worldMax, 0}
-	//   [1] = the first four pool entries in walk order: entries 1..4 after the start guard (top-down walk,
-	//         ITERATION_DIRECTION +1) or entries runCount..runCount-3 (bottom-up walk, -1)
+	// 32-byte column records, one table per element iteration direction (ITERATION_DIRECTION +1 walks a column
+	// top-down, -1 bottom-up).  The reference walks every RLE element (air runs only move the bounds, World.cs:245-259);
+	// the records hold the SOLID runs only, in walk order, with the position the walk would have reached:
+	//   [0] = {colorsBase, solidCount | worldMin << 16, worldMax | runCount << 16, overflowBase}
+	//         colorsBase   = pool index of the column's first colour (RLEColumn.ColorPointer, World.cs:185)
+	//         overflowBase = index into runsDown / runsUp of solid run 2 (valid when solidCount > 2; even = 16-byte aligned)
+	//   [1] = solid runs 0 and 1, two words each:
+	//         w0 = start | length << 16   start = voxels (of this LOD) between the walk's starting end of the column and the run
+	//         w1 = colorsIndex | elementIndex << 16   elementIndex = 1-based position of the run among ALL elements in walk order
+	//              (only the counting variant reads it: it restores the reference's element count E)
 	const uint4 *columnsDown;
 	const uint4 *columnsUp;
-	// entries 5..8 in walk order per column (read only for columns with more than 3 runs)
-	const uint4 *extDown;
-	const uint4 *extUp;
-	const uint32_t *elements; // RLEElement {int16 ColorsIndex, int16 Length} / ColorARGB32
+	const uint2 *runsDown; // solid runs 2.. of the columns that have more than two
+	const uint2 *runsUp;
+	const uint32_t *elements; // the reference's element pool (RLEElement / ColorARGB32); the kernel reads colours only
 	int32_t shift;            // lod
 	int32_t mulX;             // dimZ >> lod
 };

@@ -52,7 +52,7 @@ struct cvx_context {
 	std::string error;
 
 	// world
-	void *levelHeaders[CVX_LOD_LEVELS] = {};   // columnsDown then columnsUp, one allocation
+	void *levelHeaders[CVX_LOD_LEVELS] = {};   // columnsDown, columnsUp, runsDown, runsUp: one allocation
 	void *levelElements[CVX_LOD_LEVELS] = {};
 	bool levelSet[CVX_LOD_LEVELS] = {};
 	DevWorld hostWorld{};
@@ -512,53 +512,84 @@ int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byt
 	const RefHeader *src = static_cast<const RefHeader *>(storage);
 	const uint32_t *elements = reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(storage) + (size_t)columnCount * 12);
 
-	// Widen headers to 16 bytes and validate every column so that the kernel's
-	// element walk is guaranteed to terminate inside the pool.
-	// two tables of 32-byte records (cvx_device.h): [2*i] header, [2*i+1] element queue; down then up; then the
-	// two 16-byte-per-column extension tables (entries 5..8)
+	// Validate every column (so that nothing the kernel dereferences can leave the pool) and build the two tables of
+	// 32-byte solid-run records plus the two overflow lists (cvx_device.h).
 	const size_t columnsAlloc = (size_t)(usedColumns > 0 ? usedColumns : 1);
 	const size_t tableEntries = columnsAlloc * 2;
-	std::vector<uint4> headers(tableEntries * 2 + columnsAlloc * 2, uint4{ 0u, 0u, 0u, 0u });
-	auto entry = [&](int64_t off) -> uint32_t { return (off >= 0 && off < elementCount) ? elements[off] : 0u; };
 	const int maxY = dimY >> lod;
+	size_t overflowEntries = 2; // never empty: keeps the pointers valid
 	for (int64_t i = 0; i < usedColumns; i++) {
 		const RefHeader &h = src[i];
-		uint4 d = { 0u, 0u, 0u, 0u };
-		if (h.runCount > 0) {
-			const int64_t off = h.storageOffset;
-			if (off < 0 || off + h.runCount + 2 > elementCount) {
-				return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "column %lld: element range outside the pool", (long long)i);
-			}
-			if (elements[off] != 0u || elements[off + h.runCount + 1] != 0u) {
-				return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "column %lld: missing element guards (World.cs:205-209)", (long long)i);
-			}
-			int64_t solid = 0, total = 0;
-			for (int r = 0; r < h.runCount; r++) {
-				const uint32_t raw = elements[off + 1 + r];
-				const int colorsIndex = (int)(int16_t)(raw & 0xFFFFu);
-				const int length = (int)(int16_t)(raw >> 16);
-				if (length <= 0) {
-					return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "column %lld: run %d has length %d", (long long)i, r, length);
-				}
-				total += length;
-				if (colorsIndex >= 0) {
-					if (colorsIndex + length > solid) { solid = colorsIndex + length; }
-				}
-			}
-			if (total > maxY || off + h.runCount + 2 + solid > elementCount) {
-				return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "column %lld: runs exceed the world height or colours exceed the pool", (long long)i);
-			}
-			d.x = (uint32_t)h.storageOffset;
-			d.y = (uint32_t)h.runCount | ((uint32_t)h.worldMin << 16);
-			d.z = (uint32_t)h.worldMax;
-			headers[(size_t)i * 2 + 1] = uint4{ entry(off + 1), entry(off + 2), entry(off + 3), entry(off + 4) };
-			const int64_t last = off + h.runCount;
-			headers[tableEntries + (size_t)i * 2 + 1] = uint4{ entry(last), entry(last - 1), entry(last - 2), entry(last - 3) };
-			headers[tableEntries * 2 + (size_t)i] = uint4{ entry(off + 5), entry(off + 6), entry(off + 7), entry(off + 8) };
-			headers[tableEntries * 2 + columnsAlloc + (size_t)i] = uint4{ entry(last - 4), entry(last - 5), entry(last - 6), entry(last - 7) };
+		if (h.runCount == 0) {
+			continue;
 		}
-		headers[(size_t)i * 2] = d;
-		headers[tableEntries + (size_t)i * 2] = d;
+		const int64_t off = h.storageOffset;
+		if (off < 0 || off + h.runCount + 2 > elementCount) {
+			return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "column %lld: element range outside the pool", (long long)i);
+		}
+		if (elements[off] != 0u || elements[off + h.runCount + 1] != 0u) {
+			return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "column %lld: missing element guards (World.cs:205-209)", (long long)i);
+		}
+		int64_t colours = 0, total = 0;
+		size_t solid = 0;
+		for (int r = 0; r < h.runCount; r++) {
+			const uint32_t raw = elements[off + 1 + r];
+			const int colorsIndex = (int)(int16_t)(raw & 0xFFFFu);
+			const int length = (int)(int16_t)(raw >> 16);
+			if (length <= 0) {
+				return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "column %lld: run %d has length %d", (long long)i, r, length);
+			}
+			total += length;
+			if (colorsIndex >= 0) {
+				solid++;
+				if (colorsIndex + length > colours) { colours = colorsIndex + length; }
+			}
+		}
+		if (total > maxY || off + h.runCount + 2 + colours > elementCount) {
+			return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "column %lld: runs exceed the world height or colours exceed the pool", (long long)i);
+		}
+		if (solid > 2) {
+			overflowEntries += (solid - 2 + 1) & ~(size_t)1; // lists start 16-byte aligned
+		}
+	}
+	std::vector<uint4> headers(tableEntries * 2, uint4{ 0u, 0u, 0u, 0u });
+	std::vector<uint2> overflow(overflowEntries * 2, uint2{ 0u, 0u }); // down list, then up list
+	size_t overflowCursor = 0;
+	std::vector<uint2> walk;
+	for (int64_t i = 0; i < usedColumns; i++) {
+		const RefHeader &h = src[i];
+		if (h.runCount == 0) {
+			continue;
+		}
+		const int64_t off = h.storageOffset;
+		const int n = h.runCount;
+		size_t solid = 0;
+		for (int r = 0; r < n; r++) {
+			solid += (int16_t)(elements[off + 1 + r] & 0xFFFFu) >= 0 ? 1u : 0u;
+		}
+		const size_t listBase = overflowCursor;
+		for (int dir = 0; dir < 2; dir++) { // 0: top-down (ITERATION_DIRECTION +1), 1: bottom-up
+			walk.clear();
+			uint32_t start = 0;
+			for (int k = 0; k < n; k++) {
+				const int r = dir == 0 ? k : n - 1 - k;
+				const uint32_t raw = elements[off + 1 + r];
+				const uint32_t length = raw >> 16;
+				if ((int16_t)(raw & 0xFFFFu) >= 0) {
+					walk.push_back(uint2{ start | (length << 16), (raw & 0xFFFFu) | ((uint32_t)(k + 1) << 16) });
+				}
+				start += length;
+			}
+			uint4 *rec = headers.data() + (dir == 0 ? 0 : tableEntries) + (size_t)i * 2;
+			rec[0] = uint4{ (uint32_t)(off + n + 2), (uint32_t)solid | ((uint32_t)h.worldMin << 16), (uint32_t)h.worldMax | ((uint32_t)n << 16), (uint32_t)listBase };
+			rec[1] = uint4{ solid > 0 ? walk[0].x : 0u, solid > 0 ? walk[0].y : 0u, solid > 1 ? walk[1].x : 0u, solid > 1 ? walk[1].y : 0u };
+			for (size_t k = 2; k < solid; k++) {
+				overflow[(dir == 0 ? 0 : overflowEntries) + listBase + (k - 2)] = walk[k];
+			}
+		}
+		if (solid > 2) {
+			overflowCursor += (solid - 2 + 1) & ~(size_t)1;
+		}
 	}
 
 	CVX_HIP(ctx, hipSetDevice(ctx->device));
@@ -566,21 +597,21 @@ int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byt
 	if (ctx->levelHeaders[lod]) { (void)hipFree(ctx->levelHeaders[lod]); ctx->levelHeaders[lod] = nullptr; }
 	if (ctx->levelElements[lod]) { (void)hipFree(ctx->levelElements[lod]); ctx->levelElements[lod] = nullptr; }
 	ctx->levelSet[lod] = false;
-	CVX_HIP(ctx, hipMalloc(&ctx->levelHeaders[lod], headers.size() * sizeof(uint4)));
-	// 4 entries of zero padding on both sides: the kernel fetches element windows of 4 entries that may start
-	// up to 2 entries before / end up to 3 entries after a column's own range (cvx_kernels.h, element queue)
-	const size_t kPoolPad = 4;
+	const size_t headerBytes = headers.size() * sizeof(uint4);
+	CVX_HIP(ctx, hipMalloc(&ctx->levelHeaders[lod], headerBytes + overflow.size() * sizeof(uint2)));
+	const size_t kPoolPad = 4; // zeroed guard entries around the pool
 	CVX_HIP(ctx, hipMalloc(&ctx->levelElements[lod], ((size_t)(elementCount > 0 ? elementCount : 0) + 2 * kPoolPad) * 4));
 	CVX_HIP(ctx, hipMemset(ctx->levelElements[lod], 0, ((size_t)(elementCount > 0 ? elementCount : 0) + 2 * kPoolPad) * 4));
-	CVX_HIP(ctx, hipMemcpy(ctx->levelHeaders[lod], headers.data(), headers.size() * sizeof(uint4), hipMemcpyHostToDevice));
+	CVX_HIP(ctx, hipMemcpy(ctx->levelHeaders[lod], headers.data(), headerBytes, hipMemcpyHostToDevice));
+	CVX_HIP(ctx, hipMemcpy(static_cast<uint8_t *>(ctx->levelHeaders[lod]) + headerBytes, overflow.data(), overflow.size() * sizeof(uint2), hipMemcpyHostToDevice));
 	if (elementCount > 0) {
 		CVX_HIP(ctx, hipMemcpy(static_cast<uint32_t *>(ctx->levelElements[lod]) + kPoolPad, elements, (size_t)elementCount * 4, hipMemcpyHostToDevice));
 	}
 	DevWorldLevel &L = ctx->hostWorld.level[lod];
 	L.columnsDown = static_cast<const uint4 *>(ctx->levelHeaders[lod]);
 	L.columnsUp = L.columnsDown + tableEntries;
-	L.extDown = L.columnsDown + tableEntries * 2;
-	L.extUp = L.extDown + columnsAlloc;
+	L.runsDown = reinterpret_cast<const uint2 *>(L.columnsDown + tableEntries * 2);
+	L.runsUp = L.runsDown + overflowEntries;
 	L.elements = static_cast<const uint32_t *>(ctx->levelElements[lod]) + kPoolPad;
 	L.shift = lod;
 	L.mulX = dimZ >> lod;

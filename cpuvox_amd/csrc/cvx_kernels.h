@@ -340,7 +340,8 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 	int voxelScale = 1 << lod;
 	DevWorldLevel L = world->level[lod];
 	const int maskX = world->maskX, maskZ = world->maskZ;
-	const float worldMaxY = (float)world->dimY;
+	const int worldMaxYInt = world->dimY;
+	const float worldMaxY = (float)worldMaxYInt;
 	const float cameraPosYNormalized = posY / worldMaxY;
 	const float invWorldMaxY = 1.0f / worldMaxY; // exact: dimY is a power of two
 
@@ -377,25 +378,25 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 
 	// The column being processed ("cur") and the values of the DDA / LOD state that belong to it; `ray` itself
 	// already stands on the NEXT column, whose 32-byte record is in flight while this one is processed.
-	uint4 header, queue;              // record of the current column: header + first four elements in walk order
+	uint4 header, queue;              // record of the current column: header + its first two solid runs in walk order
 	float curDistLast, curDistNext;   // ray.IntersectionDistances of the current column
 	int curScale;                     // voxelScale of the current column
-	const uint32_t *curElements;      // element pool of the current column's LOD
-	const uint4 *curExt;              // entries 5..8 (walk order) of the current column, fetched only when it has > 3 runs
+	const uint32_t *curElements;      // element pool of the current column's LOD (colours)
+	const uint2 *curRuns;             // overflow list (solid runs 2..) of the current column's LOD and walk direction
+	unsigned int consumed = 0u;       // counting variant: elements the reference's walk has dereferenced in this column
 	float worldBoundsMin, worldBoundsMax;
 
 	// Clip, element walk and pixel writes of ExecuteRay (:289-611) for the current column;
 	// false = the ray is finished (every such exit is WriteSkybox).
 	auto drawColumn = [&]() -> bool {
-		const int columnRuns = (int)(header.y & 0xFFFFu);
+		const int solidCount = (int)(header.y & 0xFFFFu);
 		CVX_BEGIN();
-		const uint32_t *guardStart = curElements + header.x; // RLEColumn.ElementGuardStart, World.cs:175
-		uint32_t q0 = queue.x, q1 = queue.y, q2 = queue.z, q3 = queue.w;
+		if (COUNT) { consumed = 0u; }
+		const uint2 *overflowRuns = curRuns + header.w - 2; // solid run k >= 2 lives at overflowRuns[k]
 		uint4 ext = { 0u, 0u, 0u, 0u };
-		if (columnRuns > 3) {
-			ext = *curExt; // issued now, needed after four elements: the latency hides behind the clip / first run
+		if (solidCount > 2) {
+			ext = *reinterpret_cast<const uint4 *>(overflowRuns + 2); // runs 2 and 3; issued now, the latency hides behind the clip / first run
 		}
-		bool extPending = true;
 		// :289-293
 		const f3 camSpaceMinLast = f3_madd(planeStartBottom, planeDir, curDistLast);
 		const f3 camSpaceMinNext = f3_madd(planeStartBottom, planeDir, curDistNext);
@@ -455,23 +456,13 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 
 		CVX_END(2);
 		// ---- element loop, :424-611
+		// The reference walks all RLE elements of the column, starting from worldMaxY downwards (ITERATION_DIRECTION +1)
+		// or from 0 upwards (-1), :428-455; air runs only move the bounds (:457-459).  The records list the solid runs
+		// with the distance the walk has covered when it reaches them (an integer number of voxels, so the float
+		// bounds the reference accumulates are exactly these integers), so only solid runs are iterated here.
 		float elementBoundsMin, elementBoundsMax;
-		const uint32_t *elementPointer;
-		// The first four elements in walk order travel with the column record (q0..q3), so typical columns
-		// (<= 3 runs + guard) never touch the element pool; longer ones continue with single loads (the walk is
-		// a chain of dependent 4-byte loads in the reference).  Entries of the queue beyond the guard are never
-		// consumed.
-		int queued = 4;
-		if (DIR > 0) {
-			elementBoundsMin = worldMaxY;
-			elementBoundsMax = worldMaxY;
-			elementPointer = guardStart;
-		} else {
-			elementBoundsMin = 0.0f;
-			elementBoundsMax = 0.0f;
-			elementPointer = guardStart + columnRuns + 1; // ElementGuardEnd, World.cs:180
-		}
-		const uint32_t *worldColumnColors = guardStart + columnRuns + 2; // ColorPointer, World.cs:185
+		int solidIndex = 0;
+		const uint32_t *worldColumnColors = curElements + header.x; // ColorPointer, World.cs:185
 
 		// Element loop :441-611, realigned for SIMT: every lane first walks its own elements (cheap: decode,
 		// bounds bookkeeping, air / world-bounds culls :445-475) up to its next run that has to be projected;
@@ -482,50 +473,44 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			int elementColorsIndex = 0, elementLength = 0;
 			bool found = false;
 			CVX_BEGIN();
-			while (true) {
+			while (solidIndex < solidCount) {
 				CVX_COUNT(3);
-				elementPointer += DIR;
-				uint32_t raw;
-				if (queued == 0 && extPending) {
-					q0 = ext.x; q1 = ext.y; q2 = ext.z; q3 = ext.w;
-					queued = 4;
-					extPending = false;
-				}
-				if (queued > 0) {
-					raw = q0; q0 = q1; q1 = q2; q2 = q3;
-					queued--;
+				uint32_t w0, w1;
+				if (solidIndex < 4) {
+					const bool odd = (solidIndex & 1) != 0;
+					const uint4 pair = solidIndex < 2 ? queue : ext;
+					w0 = odd ? pair.z : pair.x;
+					w1 = odd ? pair.w : pair.y;
 				} else {
-					raw = *elementPointer;
+					const uint2 run = overflowRuns[solidIndex];
+					w0 = run.x;
+					w1 = run.y;
 				}
-				elementColorsIndex = (int)(short)(raw & 0xFFFFu);
-				elementLength = (int)(short)(raw >> 16);
-				if (COUNT) { cnt.E++; }
-				if (elementLength == 0) {
-					break; // guard: end of the column
-				}
-
+				solidIndex++;
+				elementLength = (int)(w0 >> 16);
+				elementColorsIndex = (int)(w1 & 0xFFFFu);
+				if (COUNT) { consumed = w1 >> 16; }
+				const int walked = (int)(w0 & 0xFFFFu) * curScale;
 				if (DIR > 0) {
-					elementBoundsMax = elementBoundsMin;
-					elementBoundsMin = elementBoundsMin - (float)(elementLength * curScale);
+					const int top = worldMaxYInt - walked;
+					elementBoundsMax = (float)top;
+					elementBoundsMin = (float)(top - elementLength * curScale);
 				} else {
-					elementBoundsMin = elementBoundsMax;
-					elementBoundsMax = elementBoundsMin + (float)(elementLength * curScale);
-				}
-
-				if (elementColorsIndex < 0) {
-					continue; // air
+					elementBoundsMin = (float)walked;
+					elementBoundsMax = (float)(walked + elementLength * curScale);
 				}
 				if (elementBoundsMin > worldBoundsMax) {
-					if (DIR < 0) { break; } else { continue; }
+					if (DIR < 0) { solidIndex = solidCount + 1; break; } else { continue; }
 				}
 				if (elementBoundsMax < worldBoundsMin) {
-					if (DIR > 0) { break; } else { continue; }
+					if (DIR > 0) { solidIndex = solidCount + 1; break; } else { continue; }
 				}
 				found = true;
 				break;
 			}
 			CVX_END(3);
 			if (!found) {
+				if (COUNT && solidIndex == solidCount) { consumed = (header.z >> 16) + 1u; } // walked on to the end guard
 				break;
 			}
 
@@ -679,8 +664,6 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 	};
 
 	const uint4 *table = DIR > 0 ? L.columnsDown : L.columnsUp;
-	const uint4 *extTable = DIR > 0 ? L.extDown : L.extUp;
-	const uint4 *nextExt;
 
 	// column 0: LOD check (:237-243), bounds test and fetch (World.GetVoxelColumn, World.cs:130-142)
 	if (ray.distLast >= lodMax && lod < 5) {
@@ -689,7 +672,6 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		voxelScale *= 2;
 		L = world->level[lod];
 		table = DIR > 0 ? L.columnsDown : L.columnsUp;
-		extTable = DIR > 0 ? L.extDown : L.extUp;
 		lodMax = F.lod[lod];
 	}
 	if ((ray.px & maskX) != ray.px || (ray.pz & maskZ) != ray.pz) {
@@ -700,7 +682,6 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		const uint4 *rec = table + 2 * column;
 		header = rec[0];
 		queue = rec[1];
-		nextExt = extTable + column;
 	}
 
 	while (true) {
@@ -715,7 +696,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		curDistNext = ray.distNext;
 		curScale = voxelScale;
 		curElements = L.elements;
-		curExt = nextExt;
+		curRuns = DIR > 0 ? L.runsDown : L.runsUp;
 		const int curLod = lod;
 		const bool lastColumn = dda_step(ray, farClip); // true: far clip reached after this column
 		// (the LOD check and the fetch are done for every lane, also one that stops after this column: its state is
@@ -726,7 +707,6 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			voxelScale *= 2;
 			L = world->level[lod];
 			table = DIR > 0 ? L.columnsDown : L.columnsUp;
-			extTable = DIR > 0 ? L.extDown : L.extUp;
 			lodMax = F.lod[lod];
 		}
 		const bool nextOutside = (ray.px & maskX) != ray.px || (ray.pz & maskZ) != ray.pz;
@@ -734,7 +714,6 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		const uint4 *rec = table + 2 * column;
 		const uint4 nextHeader = rec[0];
 		const uint4 nextQueue = rec[1];
-		nextExt = extTable + column;
 
 		// ---- the current column, exactly as the reference processes it
 		if (COUNT) {
@@ -742,7 +721,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 #pragma unroll
 			for (int k = 0; k < 6; k++) { cnt.lod[k] += (curLod == k) ? 1u : 0u; }
 		}
-		if ((header.y & 0xFFFFu) != 0u) { // not an empty column (:251-256)
+		if ((header.z >> 16) != 0u) { // RunCount > 0: not an empty column (:251-256)
 			bool draw = true;
 			worldBoundsMin = 0.0f;
 			worldBoundsMax = worldMaxY;
@@ -764,8 +743,12 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 				}
 			}
 			CVX_END(1);
-			if (draw && !drawColumn()) {
-				return;
+			if (draw) {
+				const bool goOn = drawColumn();
+				if (COUNT) { cnt.E += consumed; }
+				if (!goOn) {
+					return;
+				}
 			}
 			CVX_BEGIN();
 		}
