@@ -149,16 +149,16 @@ __device__ __forceinline__ bool dda_step(DDA &d, float farClip) // :135-150
 }
 
 // ---- CameraData helpers (Assets/Code/Utils/CameraData.cs) ------------------
-__device__ __forceinline__ float clip_min(f3 pMin, f3 pMax, float frustum) // :101-107
+// `finv` = 1 / frustum, which the reference computes inside these two (:103,111): the frustum is one of the two window bounds, so
+// the caller divides once per bound and passes the quotient in.
+__device__ __forceinline__ float clip_min(f3 pMin, f3 pMax, float finv) // :101-107
 {
-	float finv = 1.0f / frustum;
 	float c0 = 1.0f * pMax.z - finv * pMax.x;
 	float c1 = 1.0f * pMin.z - finv * pMin.x;
 	return 1.0f - (c0 / (c0 - c1));
 }
-__device__ __forceinline__ float clip_max(f3 pMin, f3 pMax, float frustum) // :109-115
+__device__ __forceinline__ float clip_max(f3 pMin, f3 pMax, float finv) // :109-115
 {
-	float finv = 1.0f / frustum;
 	float c0 = 1.0f * pMax.z - finv * pMax.x;
 	float c1 = 1.0f * pMin.z - finv * pMin.x;
 	return c1 / (c1 - c0);
@@ -169,7 +169,7 @@ __device__ __forceinline__ float clip_max(f3 pMin, f3 pMax, float frustum) // :1
 // evaluates at most one "min" clip (against fMax when a1, else against fMin when b1) and at most one "max" clip (against
 // fMax when a2 and not a1, else against fMin when b2); the arithmetic of each is the tree's own, so the values are the
 // same, but divergent lanes of a wave now share one instance of each division sequence instead of six.
-__device__ __forceinline__ bool clip_world_bounds(f3 pMin, f3 pMax, float fMin, float fMax, float &minLerp, float &maxLerp)
+__device__ __forceinline__ bool clip_world_bounds(f3 pMin, f3 pMax, float fMin, float fMax, float invFMin, float invFMax, float &minLerp, float &maxLerp)
 {
 	const bool a1 = pMin.x > pMin.z * fMax;
 	const bool a2 = pMax.x > pMax.z * fMax;
@@ -177,8 +177,8 @@ __device__ __forceinline__ bool clip_world_bounds(f3 pMin, f3 pMax, float fMin, 
 	const bool b2 = pMax.x < pMax.z * fMin;
 	const bool needMin = a1 || b1;
 	const bool needMax = a1 ? b2 : (a2 || b2);
-	const float lo = clip_min(pMin, pMax, a1 ? fMax : fMin);
-	const float hi = clip_max(pMin, pMax, (!a1 && a2) ? fMax : fMin);
+	const float lo = clip_min(pMin, pMax, a1 ? invFMax : invFMin);
+	const float hi = clip_max(pMin, pMax, (!a1 && a2) ? invFMax : invFMin);
 	minLerp = needMin ? lo : 0.0f;
 	maxLerp = needMax ? hi : 1.0f;
 	return a1 ? a2 : (!a2 && b1 && b2);
@@ -407,8 +407,9 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		if (curDistLast > 2.0f && frustumDirMaxWorld == CVX_FLOAT_EPSILON) { // :295-422
 			CVX_COUNT(2);
 			float clipLastMinLerp, clipLastMaxLerp, clipNextMinLerp, clipNextMaxLerp;
-			const bool clippedLast = clip_world_bounds(camSpaceMinLast, camSpaceMaxLast, frustumBoundsMin, frustumBoundsMax, clipLastMinLerp, clipLastMaxLerp);
-			const bool clippedNext = clip_world_bounds(camSpaceMinNext, camSpaceMaxNext, frustumBoundsMin, frustumBoundsMax, clipNextMinLerp, clipNextMaxLerp);
+			const float invFrustumMin = 1.0f / frustumBoundsMin, invFrustumMax = 1.0f / frustumBoundsMax; // CameraData.cs:103,111
+			const bool clippedLast = clip_world_bounds(camSpaceMinLast, camSpaceMaxLast, frustumBoundsMin, frustumBoundsMax, invFrustumMin, invFrustumMax, clipLastMinLerp, clipLastMaxLerp);
+			const bool clippedNext = clip_world_bounds(camSpaceMinNext, camSpaceMaxNext, frustumBoundsMin, frustumBoundsMax, invFrustumMin, invFrustumMax, clipNextMinLerp, clipNextMaxLerp);
 
 			if (clippedLast && clippedNext) {
 				return false;
