@@ -1,0 +1,229 @@
+// cvx_downsample.h -- World.DownSample (Assets/Code/World.cs:45-127) on the device (gfx950).
+//
+// The reference builds LOD j by pushing every voxel of the (2^j)^2 source columns under a target column into an
+// RLEColumnBuilder with Y >> j (DownSamplePartial, :101-127), then sorting by Y, averaging the colours of voxels that
+// share a Y and run-length encoding the result (RLEColumnBuilder.ToFinalColumn, WordBuilder.cs:181-268).  Byte work,
+// no floating point.  Here: one wave per target column; the source voxels are accumulated into per-target-Y buckets
+// in LDS (sum r, g, b, count with ds_add; the alpha of the FIRST voxel in the reference's insertion order with a
+// 64-bit ds_min on {source column, sequence, alpha}), then the buckets are scanned top-down 64 at a time: a ballot
+// gives the occupancy word, runs are cut out of it with ctz, colour slots are popcount prefixes.  Two passes over the
+// same code: pass 1 counts runs / colours per column, an exclusive scan assigns element offsets in column order (the
+// deterministic order of the host build, cvx_world.cpp BuildColumns), pass 2 writes headers, guards, runs, colours
+// in the reference's storage layout (World.cs:161-169, 190-209) so the blob is byte-identical to the host's.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cvxk {
+
+#define CVX_DS_BUCKETS 2048 /* at most this many target-Y buckets are held in LDS per pass over the sources (48 KB) */
+
+struct DownsampleParams {
+	const uint32_t *srcHeaders;  // 12-byte RLEColumn headers as 3 words each
+	const uint32_t *srcElements; // element / colour pool
+	int srcLod, extraLods;
+	int dimY;
+	int srcMulX;        // dimZ >> srcLod
+	int targetColumnsZ; // dimZ >> (srcLod + extraLods)
+	int targetColumns;
+	int chunkBuckets;   // buckets per pass over the sources: min(dimY >> target lod, CVX_DS_BUCKETS)
+};
+
+struct DownsampleOut {
+	uint32_t *alloc;     // pass 1 out / pass 2 in (after the scan: element offset of the column)
+	uint32_t *runCounts; // pass 1 out / pass 2 in
+	uint32_t *headers;   // pass 2: 3 words per target column (table zero-initialised by the host)
+	uint32_t *elements;  // pass 2
+	unsigned long long *voxelCount;
+	int *error; // 1: a column needs more than 65535 runs (World.cs:193-195)
+};
+
+template <bool WRITE>
+__global__ __launch_bounds__(64) void downsample_kernel(DownsampleParams P, DownsampleOut O)
+{
+	// dynamic LDS: `chunk` = min(target height, CVX_DS_BUCKETS) buckets of 24 bytes (the launch passes chunk * 24)
+	extern __shared__ unsigned long long dsLds[];
+	const int chunk = P.chunkBuckets;
+	unsigned long long *first = dsLds;
+	uint32_t *sumR = reinterpret_cast<uint32_t *>(dsLds + chunk), *sumG = sumR + chunk, *sumB = sumG + chunk, *count = sumB + chunk;
+
+	const int lane = threadIdx.x;
+	const int k = blockIdx.x;
+	const int targetLod = P.srcLod + P.extraLods;
+	const int step = 1 << targetLod, stepSize = 1 << P.srcLod, steps = 1 << P.extraLods;
+	const int xStart = (k / P.targetColumnsZ) * step, zStart = (k % P.targetColumnsZ) * step;
+	const int srcHeight = P.dimY >> P.srcLod;
+	const int topY = (P.dimY >> targetLod) - 1;
+
+	// wave-uniform emit state
+	int runLen = 0, runColorsIndex = 0, runs = 0, solid = 0;
+	bool runSolid = false;
+	int highest = -1, lowest = 0;
+	uint32_t elemBase = 0, colourBase = 0;
+	if (WRITE) {
+		if (O.runCounts[k] == 0u) {
+			return; // empty column: the header stays zero
+		}
+		elemBase = O.alloc[k];
+		colourBase = elemBase + O.runCounts[k] + 2u;
+	}
+	auto flushRun = [&]() {
+		if (runLen > 0) {
+			if (WRITE && lane == 0) {
+				O.elements[elemBase + 1u + (uint32_t)runs] = (uint32_t)(runSolid ? (runColorsIndex & 0xFFFF) : 0xFFFF) | ((uint32_t)runLen << 16);
+			}
+			runs++;
+			runLen = 0;
+		}
+	};
+
+	for (int chunkTop = topY; chunkTop >= 0; chunkTop -= chunk) {
+		const int chunkLo = chunkTop - chunk + 1 > 0 ? chunkTop - chunk + 1 : 0;
+		const int buckets = chunkTop - chunkLo + 1;
+		for (int b = lane; b < buckets; b += 64) {
+			sumR[b] = sumG[b] = sumB[b] = count[b] = 0u;
+			first[b] = ~0ull;
+		}
+		__syncthreads();
+
+		// DownSamplePartial for source column s = ix * steps + iz (the reference's insertion order, World.cs:85-94)
+		for (int s = lane; s < steps * steps; s += 64) {
+			const int x = xStart + (s / steps) * stepSize, z = zStart + (s % steps) * stepSize;
+			const uint32_t *h = P.srcHeaders + 3 * (size_t)((x >> P.srcLod) * P.srcMulX + (z >> P.srcLod));
+			const uint32_t offset = h[0];
+			const int runCount = (int)(h[1] & 0xFFFFu);
+			if (runCount == 0) {
+				continue;
+			}
+			const uint32_t *guardStart = P.srcElements + offset;
+			const uint32_t *colours = guardStart + runCount + 2;
+			int elementBoundsX = srcHeight;
+			uint32_t seq = 0;
+			for (int run = 0; run < runCount; run++) {
+				const uint32_t raw = guardStart[run + 1];
+				const int length = (int)(int16_t)(raw >> 16);
+				const int colorsIndex = (int)(int16_t)(raw & 0xFFFFu);
+				elementBoundsX -= length;
+				if (colorsIndex < 0) {
+					continue;
+				}
+				// voxels i of the run with chunkLo <= (elementBoundsX + i) >> extraLods <= chunkTop
+				int iFrom = (chunkLo << P.extraLods) - elementBoundsX;
+				int iTo = ((chunkTop + 1) << P.extraLods) - elementBoundsX; // exclusive
+				if (iFrom < 0) { iFrom = 0; }
+				if (iTo > length) { iTo = length; }
+				for (int i = iFrom; i < iTo; i++) {
+					const int b = ((elementBoundsX + i) >> P.extraLods) - chunkLo;
+					const uint32_t c = colours[colorsIndex + length - i - 1]; // bytes a, r, g, b
+					atomicAdd(&sumR[b], (c >> 8) & 0xFFu);
+					atomicAdd(&sumG[b], (c >> 16) & 0xFFu);
+					atomicAdd(&sumB[b], c >> 24);
+					atomicAdd(&count[b], 1u);
+					atomicMin(&first[b], ((unsigned long long)s << 40) | ((unsigned long long)(seq + (uint32_t)i) << 8) | (c & 0xFFu));
+				}
+				seq += (uint32_t)length;
+			}
+		}
+		__syncthreads();
+
+		// ToFinalColumn over this chunk, top-down, 64 buckets per step (lane 0 = highest Y)
+		for (int g = chunkTop; g >= chunkLo; g -= 64) {
+			const int y = g - lane;
+			const bool valid = y >= chunkLo;
+			const uint32_t n = valid ? count[y - chunkLo] : 0u;
+			const unsigned long long occupied = __ballot(n > 0u);
+			const int nValid = g - chunkLo + 1 < 64 ? g - chunkLo + 1 : 64;
+			if (WRITE && n > 0u) {
+				const int b = y - chunkLo;
+				const uint32_t slot = (uint32_t)solid + (uint32_t)__popcll(occupied & ((1ull << lane) - 1ull));
+				O.elements[colourBase + slot] = (uint32_t)(first[b] & 0xFFull) | ((sumR[b] / n) << 8) | ((sumG[b] / n) << 16) | ((sumB[b] / n) << 24);
+			}
+			if (occupied != 0ull) {
+				if (highest < 0) {
+					highest = g - (__ffsll((long long)occupied) - 1);
+				}
+				lowest = g - (63 - __clzll((long long)occupied));
+			}
+			int pos = 0;
+			while (pos < nValid) { // wave-uniform: cut the occupancy word into maximal runs
+				const bool bit = ((occupied >> pos) & 1ull) != 0ull;
+				const unsigned long long differing = (bit ? ~occupied : occupied) >> pos;
+				int len = differing == 0ull ? 64 - pos : __ffsll((long long)differing) - 1;
+				if (len > nValid - pos) { len = nValid - pos; }
+				if (runLen > 0 && runSolid != bit) {
+					flushRun();
+				}
+				if (runLen == 0) {
+					runSolid = bit;
+					runColorsIndex = solid + __popcll(occupied & ((1ull << pos) - 1ull));
+				}
+				runLen += len;
+				pos += len;
+			}
+			solid += __popcll(occupied);
+		}
+		__syncthreads();
+	}
+	flushRun();
+
+	if (solid == 0) {
+		if (!WRITE && lane == 0) {
+			O.alloc[k] = 0u;
+			O.runCounts[k] = 0u;
+		}
+		return;
+	}
+	if (lane == 0) {
+		if (!WRITE) {
+			if (runs > 65535) {
+				*O.error = 1;
+			}
+			O.alloc[k] = (uint32_t)(runs + solid + 2);
+			O.runCounts[k] = (uint32_t)runs;
+			atomicAdd(O.voxelCount, (unsigned long long)solid);
+		} else {
+			const uint32_t voxelScale = 1u << targetLod;
+			const uint32_t worldMin = ((uint32_t)lowest * voxelScale) & 0xFFFFu;        // (ushort) casts of World.cs:231-232
+			const uint32_t worldMax = ((uint32_t)(highest + 1) * voxelScale) & 0xFFFFu;
+			O.headers[3 * (size_t)k + 0] = elemBase;
+			O.headers[3 * (size_t)k + 1] = (uint32_t)runs | (worldMin << 16);
+			O.headers[3 * (size_t)k + 2] = worldMax;
+			O.elements[elemBase] = 0u;                      // element guards, World.cs:205-209
+			O.elements[elemBase + 1u + (uint32_t)runs] = 0u;
+		}
+	}
+}
+
+// Exclusive prefix sum of n counts in place (one workgroup; n is a few million at most); *total receives the sum.
+__global__ __launch_bounds__(1024) void exclusive_scan_kernel(uint32_t *values, int n, unsigned long long *total)
+{
+	__shared__ unsigned long long partial[1024];
+	const int t = threadIdx.x;
+	const long long per = ((long long)n + 1023) / 1024;
+	const long long begin = per * t < n ? per * t : n;
+	const long long end = begin + per < n ? begin + per : n;
+	unsigned long long sum = 0;
+	for (long long i = begin; i < end; i++) {
+		sum += values[i];
+	}
+	partial[t] = sum;
+	__syncthreads();
+	for (int o = 1; o < 1024; o <<= 1) { // Hillis-Steele inclusive scan of the partials
+		const unsigned long long add = t >= o ? partial[t - o] : 0ull;
+		__syncthreads();
+		partial[t] += add;
+		__syncthreads();
+	}
+	unsigned long long running = t > 0 ? partial[t - 1] : 0ull;
+	if (t == 1023) {
+		*total = partial[1023];
+	}
+	for (long long i = begin; i < end; i++) {
+		const uint32_t v = values[i];
+		values[i] = (uint32_t)running; // callers check *total < 2^31 before using the offsets
+		running += v;
+	}
+}
+
+} // namespace cvxk

@@ -16,6 +16,7 @@
 #include "cpuvox_gpu.h"
 #include "cvx_device.h"
 #include "cvx_kernels.h"
+#include "cvx_downsample.h"
 
 namespace {
 
@@ -493,6 +494,44 @@ int cvx_set_stream(cvx_context *ctx, void *hipStream)
 	return CVX_OK;
 }
 
+namespace {
+
+// One column of a world blob in the reference's layout (World.cs:161-209): element range inside the pool, both
+// guards present, positive run lengths that fit the column height, colours inside the pool.  Everything the kernels
+// dereference later is covered here.  *solidRuns receives the number of solid runs.
+int ValidateColumn(cvx_context *ctx, int64_t i, const RefHeader &h, const uint32_t *elements, int64_t elementCount, int maxY, size_t *solidRuns)
+{
+	const int64_t off = h.storageOffset;
+	if (off < 0 || off + h.runCount + 2 > elementCount) {
+		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "column %lld: element range outside the pool", (long long)i);
+	}
+	if (elements[off] != 0u || elements[off + h.runCount + 1] != 0u) {
+		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "column %lld: missing element guards (World.cs:205-209)", (long long)i);
+	}
+	int64_t colours = 0, total = 0;
+	size_t solid = 0;
+	for (int r = 0; r < h.runCount; r++) {
+		const uint32_t raw = elements[off + 1 + r];
+		const int colorsIndex = (int)(int16_t)(raw & 0xFFFFu);
+		const int length = (int)(int16_t)(raw >> 16);
+		if (length <= 0) {
+			return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "column %lld: run %d has length %d", (long long)i, r, length);
+		}
+		total += length;
+		if (colorsIndex >= 0) {
+			solid++;
+			if (colorsIndex + length > colours) { colours = colorsIndex + length; }
+		}
+	}
+	if (total > maxY || off + h.runCount + 2 + colours > elementCount) {
+		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "column %lld: runs exceed the world height or colours exceed the pool", (long long)i);
+	}
+	*solidRuns = solid;
+	return CVX_OK;
+}
+
+} // namespace
+
 int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byteLength, int dimX, int dimY, int dimZ, int columnCount)
 {
 	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
@@ -523,30 +562,10 @@ int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byt
 		if (h.runCount == 0) {
 			continue;
 		}
-		const int64_t off = h.storageOffset;
-		if (off < 0 || off + h.runCount + 2 > elementCount) {
-			return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "column %lld: element range outside the pool", (long long)i);
-		}
-		if (elements[off] != 0u || elements[off + h.runCount + 1] != 0u) {
-			return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "column %lld: missing element guards (World.cs:205-209)", (long long)i);
-		}
-		int64_t colours = 0, total = 0;
 		size_t solid = 0;
-		for (int r = 0; r < h.runCount; r++) {
-			const uint32_t raw = elements[off + 1 + r];
-			const int colorsIndex = (int)(int16_t)(raw & 0xFFFFu);
-			const int length = (int)(int16_t)(raw >> 16);
-			if (length <= 0) {
-				return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "column %lld: run %d has length %d", (long long)i, r, length);
-			}
-			total += length;
-			if (colorsIndex >= 0) {
-				solid++;
-				if (colorsIndex + length > colours) { colours = colorsIndex + length; }
-			}
-		}
-		if (total > maxY || off + h.runCount + 2 + colours > elementCount) {
-			return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "column %lld: runs exceed the world height or colours exceed the pool", (long long)i);
+		const int rc = ValidateColumn(ctx, i, h, elements, elementCount, maxY, &solid);
+		if (rc != CVX_OK) {
+			return rc;
 		}
 		if (solid > 2) {
 			overflowEntries += (solid - 2 + 1) & ~(size_t)1; // lists start 16-byte aligned
@@ -1003,6 +1022,143 @@ int cvx_debug_section_cycles(cvx_context *ctx, uint64_t out[32], int reset)
 	for (int i = 0; i < 32; i++) { out[i] = 0; }
 	return Fail(ctx, CVX_ERR_NOT_READY, "library was not built with -DCVX_PROFILE_SECTIONS (diagnostic build)");
 #endif
+}
+
+/* World.DownSample(extraLods), World.cs:45-127, on the device (cvx_downsample.h). */
+int cvx_world_downsample(cvx_context *ctx, const void *storage, int64_t byteLength, int dimX, int dimY, int dimZ, int lod, int columnCount, int extraLods,
+                         void **outStorage, int64_t *outByteLength, int32_t *outColumnCount, int64_t *outVoxelCount, float *outDeviceMs)
+{
+	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
+	if (!storage || !outStorage || !outByteLength || !outColumnCount) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "bad arguments"); }
+	*outStorage = nullptr;
+	if (!IsPow2(dimX) || !IsPow2(dimY) || !IsPow2(dimZ) || dimY > 65536) {
+		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "world dimensions must be powers of two (WordBuilder.cs:30), Y <= 65536");
+	}
+	const int targetLod = lod + extraLods;
+	if (lod < 0 || extraLods < 1 || targetLod > 15 || (dimX >> targetLod) < 1 || (dimY >> targetLod) < 1 || (dimZ >> targetLod) < 1 || extraLods > 8) {
+		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "lod %d + extraLods %d out of range for these dimensions", lod, extraLods);
+	}
+	const int64_t usedColumns = (int64_t)(dimX >> lod) * (dimZ >> lod);
+	if (columnCount < usedColumns || (int64_t)columnCount * 12 > byteLength) {
+		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "columnCount %d inconsistent with dims/lod/byteLength", columnCount);
+	}
+	const int64_t elementCount = (byteLength - (int64_t)columnCount * 12) / 4;
+	const RefHeader *src = static_cast<const RefHeader *>(storage);
+	const uint32_t *elements = reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(storage) + (size_t)columnCount * 12);
+	for (int64_t i = 0; i < usedColumns; i++) {
+		if (src[i].runCount == 0) { continue; }
+		size_t solid = 0;
+		const int rc = ValidateColumn(ctx, i, src[i], elements, elementCount, dimY >> lod, &solid);
+		if (rc != CVX_OK) { return rc; }
+	}
+	const int64_t targetColumns = (int64_t)(dimX >> targetLod) * (dimZ >> targetLod);
+	const int64_t allocatedColumns = ((int64_t)dimX * dimZ) / ((int64_t)(targetLod + 1) * (targetLod + 1)); // World.ColumnCount, World.cs:17
+	if (targetColumns > 0x7FFFFFFF || allocatedColumns > 0x7FFFFFFF || allocatedColumns < targetColumns) {
+		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "target LOD has an unsupported column count");
+	}
+
+	CVX_HIP(ctx, hipSetDevice(ctx->device));
+	uint8_t *dSrc = nullptr;
+	uint32_t *dAlloc = nullptr, *dHeaders = nullptr, *dElements = nullptr;
+	unsigned long long *dScalars = nullptr; // [0] voxel count, [1] element total, [2] error flag
+	hipEvent_t evBegin = nullptr, evEnd = nullptr;
+	void *host = nullptr;
+	int rc = CVX_OK;
+	auto release = [&]() {
+		if (dSrc) { (void)hipFree(dSrc); }
+		if (dAlloc) { (void)hipFree(dAlloc); }
+		if (dHeaders) { (void)hipFree(dHeaders); }
+		if (dElements) { (void)hipFree(dElements); }
+		if (dScalars) { (void)hipFree(dScalars); }
+		if (evBegin) { (void)hipEventDestroy(evBegin); }
+		if (evEnd) { (void)hipEventDestroy(evEnd); }
+	};
+#define CVX_DS(call)                                                                                                      \
+	do {                                                                                                                  \
+		hipError_t e_ = (call);                                                                                           \
+		if (e_ != hipSuccess) {                                                                                           \
+			rc = Fail(ctx, CVX_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__);       \
+			release();                                                                                                    \
+			std::free(host);                                                                                              \
+			return rc;                                                                                                    \
+		}                                                                                                                 \
+	} while (0)
+	const size_t headerWords = (size_t)allocatedColumns * 3;
+	CVX_DS(hipMalloc((void **)&dSrc, (size_t)byteLength));
+	CVX_DS(hipMalloc((void **)&dAlloc, (size_t)targetColumns * 2 * sizeof(uint32_t)));
+	CVX_DS(hipMalloc((void **)&dHeaders, headerWords * sizeof(uint32_t)));
+	CVX_DS(hipMalloc((void **)&dScalars, 3 * sizeof(unsigned long long)));
+	CVX_DS(hipEventCreate(&evBegin));
+	CVX_DS(hipEventCreate(&evEnd));
+	CVX_DS(hipMemcpyAsync(dSrc, storage, (size_t)byteLength, hipMemcpyHostToDevice, ctx->stream));
+	CVX_DS(hipMemsetAsync(dHeaders, 0, headerWords * sizeof(uint32_t), ctx->stream));
+	CVX_DS(hipMemsetAsync(dScalars, 0, 3 * sizeof(unsigned long long), ctx->stream));
+
+	cvxk::DownsampleParams P{};
+	P.srcHeaders = reinterpret_cast<const uint32_t *>(dSrc);
+	P.srcElements = reinterpret_cast<const uint32_t *>(dSrc + (size_t)columnCount * 12);
+	P.srcLod = lod;
+	P.extraLods = extraLods;
+	P.dimY = dimY;
+	P.srcMulX = dimZ >> lod;
+	P.targetColumnsZ = dimZ >> targetLod;
+	P.targetColumns = (int)targetColumns;
+	P.chunkBuckets = std::min(dimY >> targetLod, CVX_DS_BUCKETS);
+	const size_t dsLdsBytes = (size_t)P.chunkBuckets * 24;
+	cvxk::DownsampleOut O{};
+	O.alloc = dAlloc;
+	O.runCounts = dAlloc + targetColumns;
+	O.headers = dHeaders;
+	O.voxelCount = dScalars;
+	O.error = reinterpret_cast<int *>(dScalars + 2);
+
+	CVX_DS(hipEventRecord(evBegin, ctx->stream));
+	hipLaunchKernelGGL((cvxk::downsample_kernel<false>), dim3((unsigned)targetColumns), dim3(64), dsLdsBytes, ctx->stream, P, O);
+	hipLaunchKernelGGL(cvxk::exclusive_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, dAlloc, (int)targetColumns, dScalars + 1);
+	CVX_DS(hipGetLastError());
+	unsigned long long scalars[3] = { 0, 0, 0 };
+	CVX_DS(hipMemcpyAsync(scalars, dScalars, sizeof scalars, hipMemcpyDeviceToHost, ctx->stream));
+	CVX_DS(hipStreamSynchronize(ctx->stream));
+	if ((int)scalars[2] != 0) {
+		release();
+		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "a downsampled column needs more than 65535 runs (World.cs:193-195)");
+	}
+	if (scalars[1] > 0x7FFFFFFFull) {
+		release();
+		return Fail(ctx, CVX_ERR_CAPACITY, "Only supports up to 2^31 elements (World.cs:355-357)");
+	}
+	const size_t elementTotal = (size_t)scalars[1];
+	CVX_DS(hipMalloc((void **)&dElements, (elementTotal > 0 ? elementTotal : 1) * sizeof(uint32_t)));
+	O.elements = dElements;
+	hipLaunchKernelGGL((cvxk::downsample_kernel<true>), dim3((unsigned)targetColumns), dim3(64), dsLdsBytes, ctx->stream, P, O);
+	CVX_DS(hipGetLastError());
+	CVX_DS(hipEventRecord(evEnd, ctx->stream));
+	const size_t outBytes = headerWords * 4 + elementTotal * 4;
+	host = std::malloc(outBytes > 0 ? outBytes : 1);
+	if (!host) {
+		release();
+		return Fail(ctx, CVX_ERR_HIP, "out of host memory");
+	}
+	CVX_DS(hipMemcpyAsync(host, dHeaders, headerWords * 4, hipMemcpyDeviceToHost, ctx->stream));
+	if (elementTotal > 0) {
+		CVX_DS(hipMemcpyAsync(static_cast<uint8_t *>(host) + headerWords * 4, dElements, elementTotal * 4, hipMemcpyDeviceToHost, ctx->stream));
+	}
+	CVX_DS(hipStreamSynchronize(ctx->stream));
+	float ms = 0.0f;
+	CVX_DS(hipEventElapsedTime(&ms, evBegin, evEnd));
+#undef CVX_DS
+	release();
+	*outStorage = host;
+	*outByteLength = (int64_t)outBytes;
+	*outColumnCount = (int32_t)allocatedColumns;
+	if (outVoxelCount) { *outVoxelCount = (int64_t)scalars[0]; }
+	if (outDeviceMs) { *outDeviceMs = ms; }
+	return CVX_OK;
+}
+
+void cvx_free(void *p)
+{
+	std::free(p);
 }
 
 int cvx_selftest_math(cvx_context *ctx, int op, int n, const float *a, const float *b, float *out)

@@ -3,6 +3,7 @@
 
 #include <cstring>
 #include <exception>
+#include <chrono>
 #include <memory>
 #include <string>
 #include <vector>
@@ -92,6 +93,39 @@ int cvxh_world_save(const cvxh_world_set *worlds, const char *path)
 }
 
 void cvxh_world_free(cvxh_world_set *worlds) { delete worlds; }
+
+int cvxh_world_from_blobs(int dimX, int dimY, int dimZ, int count, const void *const *blobs, const int64_t *byteLengths, cvxh_world_set **out)
+{
+	if (!out || !blobs || !byteLengths || count <= 0 || dimX <= 0 || dimY <= 0 || dimZ <= 0) { return Fail("bad argument"); }
+	try {
+		auto set = std::make_unique<cvxh_world_set>();
+		cvx::int3 dims; dims.x = dimX; dims.y = dimY; dims.z = dimZ;
+		for (int i = 0; i < count; i++) {
+			const int64_t headerBytes = ((int64_t)dimX * dimZ) / ((int64_t)(i + 1) * (i + 1)) * 12; // World.ColumnCount, World.cs:17
+			if (!blobs[i] || byteLengths[i] < headerBytes) { return Fail("blob " + std::to_string(i) + " is shorter than its column table"); }
+			set->worlds.emplace_back(dims, i, blobs[i], byteLengths[i]);
+		}
+		*out = set.release();
+	} catch (const std::exception &e) {
+		return Fail(e.what());
+	}
+	return CVX_OK;
+}
+
+int cvxh_world_downsample_seconds(const cvxh_world_set *worlds, int extraLods, int threads, double *outSeconds, int64_t *outVoxelCount)
+{
+	if (!worlds || worlds->worlds.empty() || extraLods < 1 || !outSeconds) { return Fail("bad argument"); }
+	try {
+		int64_t voxels = 0;
+		const auto t0 = std::chrono::steady_clock::now();
+		cvx::World lod = worlds->worlds[0].DownSample(extraLods, &voxels, threads);
+		*outSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+		if (outVoxelCount) { *outVoxelCount = voxels; }
+	} catch (const std::exception &e) {
+		return Fail(e.what());
+	}
+	return CVX_OK;
+}
 
 int cvxh_world_lod_count(const cvxh_world_set *worlds) { return worlds ? (int)worlds->worlds.size() : 0; }
 

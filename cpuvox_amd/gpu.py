@@ -29,6 +29,7 @@ EXPORTS = [
     "cvx_clear_raybuffer", "cvx_read_raybuffer", "cvx_blit_segments", "cvx_raybuffer_device_ptr",
     "cvx_screen_device_ptr", "cvx_last_draw_ms", "cvx_enable_counters", "cvx_get_counters",
     "cvx_get_raybuffer_layout", "cvx_selftest_math", "cvx_version", "cvx_bind_raybuffers", "cvx_draw_time_stats", "cvx_debug_section_cycles", "cvx_debug_occupancy", "cvx_copy_rows", "cvx_draw_segments_placed",
+    "cvx_world_downsample", "cvx_free",
 ]
 
 
@@ -94,6 +95,10 @@ def lib() -> C.CDLL:
         L.cvx_copy_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
         L.cvx_debug_section_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
         L.cvx_selftest_math.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cvx_world_downsample.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_float)]
+        L.cvx_free.argtypes = [C.c_void_p]
+        L.cvx_free.restype = None
         _lib = L
     return _lib
 
@@ -140,6 +145,27 @@ class Context:
         for lod in range(world_set.lod_count):
             i = world_set.info(lod)
             self._check(lib().cvx_world_upload(self._h, lod, i.storage, i.byteLength, i.dimX, i.dimY, i.dimZ, i.columnCount))
+
+    def downsample(self, world_set: WorldSet, lod: int, extra_lods: int):
+        """World.DownSample(extraLods) (World.cs:45) of level `lod` on the device.  Returns (blob bytes in the reference's
+        storage layout, ColumnCount of the new level, voxel count, device milliseconds)."""
+        i = world_set.info(lod)
+        out, nbytes, columns, voxels, ms = C.c_void_p(), C.c_int64(), C.c_int32(), C.c_int64(), C.c_float()
+        self._check(lib().cvx_world_downsample(self._h, i.storage, i.byteLength, i.dimX, i.dimY, i.dimZ, i.lod, i.columnCount, extra_lods,
+                                               C.byref(out), C.byref(nbytes), C.byref(columns), C.byref(voxels), C.byref(ms)))
+        try:
+            blob = C.string_at(out.value, nbytes.value)
+        finally:
+            lib().cvx_free(out)
+        return blob, columns.value, voxels.value, ms.value
+
+    def build_lods(self, world_set: WorldSet, levels: int = LOD_LEVELS) -> WorldSet:
+        """UnityManager.cs:328-331 (`worldLODs[i] = worldLODs[0].DownSample(i)`) with the downsampling on the device:
+        a new world set with LOD 0 taken from `world_set` and LOD 1..levels-1 built by cvx_world_downsample."""
+        blobs = [world_set.storage(0)]
+        for extra in range(1, levels):
+            blobs.append(self.downsample(world_set, 0, extra)[0])
+        return WorldSet.from_blobs(world_set.dims, blobs)
 
     def set_resolution(self, width: int, height: int) -> None:
         """RenderManager.SetResolution (RenderManager.cs:94-109)."""

@@ -100,6 +100,8 @@ def lib() -> C.CDLL:
         L.cvxh_world_procedural.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.POINTER(C.c_void_p)]
         L.cvxh_world_load.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
         L.cvxh_world_save.argtypes = [C.c_void_p, C.c_char_p]
+        L.cvxh_world_from_blobs.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p)]
+        L.cvxh_world_downsample_seconds.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         L.cvxh_world_free.argtypes = [C.c_void_p]
         L.cvxh_world_free.restype = None
         L.cvxh_world_lod_count.argtypes = [C.c_void_p]
@@ -167,6 +169,23 @@ class WorldSet:
         finally:
             lib().cvxh_world_builder_free(b)
         return WorldSet(h.value)
+
+    @staticmethod
+    def from_blobs(dims, blobs) -> "WorldSet":
+        """One storage blob (bytes / uint8 array, the reference's layout) per LOD, e.g. LOD 0 from the host build and the
+        rest from cpuvox_amd.gpu.Context.downsample."""
+        arrays = [np.frombuffer(b, dtype=np.uint8) if isinstance(b, (bytes, bytearray)) else np.ascontiguousarray(b, dtype=np.uint8) for b in blobs]
+        ptrs = (C.c_void_p * len(arrays))(*[a.ctypes.data for a in arrays])
+        lens = (C.c_int64 * len(arrays))(*[a.size for a in arrays])
+        h = C.c_void_p()
+        _check(lib().cvxh_world_from_blobs(int(dims[0]), int(dims[1]), int(dims[2]), len(arrays), ptrs, lens, C.byref(h)))
+        return WorldSet(h.value)
+
+    def downsample_host_seconds(self, extra_lods: int, threads: int = 0):
+        """Wall-clock seconds (and voxel count) of World.DownSample(extra_lods) of LOD 0 on the host; the result is discarded."""
+        sec, vox = C.c_double(), C.c_int64()
+        _check(lib().cvxh_world_downsample_seconds(self._h, extra_lods, threads, C.byref(sec), C.byref(vox)))
+        return sec.value, vox.value
 
     # -- accessors --------------------------------------------------------
     def save(self, path: str) -> None:

@@ -223,6 +223,17 @@ int cvx_debug_occupancy(cvx_context *ctx, int64_t ldsBytes, int *blocksPerCU);
  * 6 top/bottom setup, 7 top/bottom pixels, 8 skybox pass.  The regular build returns CVX_ERR_NOT_READY. */
 int cvx_debug_section_cycles(cvx_context *ctx, uint64_t out[32], int reset); /* [16+i] = cycles/16 * active lanes of section i */
 
+/* World.DownSample(extraLods) (Assets/Code/World.cs:45-127: DownSampleColumn :71-96, DownSamplePartial :101-127, with
+ * RLEColumnBuilder.ToFinalColumn WordBuilder.cs:181-268 and the RLEColumn constructor World.cs:190-234) as a device
+ * kernel: builds LOD lod+extraLods from the LOD `lod` blob (same layout as cvx_world_upload takes) and returns the new
+ * blob in the reference's storage layout, byte-identical to the host build (columns stored in index order), in memory
+ * owned by the library: release it with cvx_free.  outColumnCount = World.ColumnCount of the new level (World.cs:17),
+ * outVoxelCount (may be NULL) = voxels after deduplication, outDeviceMs (may be NULL) = device time of the two passes
+ * and the offset scan. */
+int cvx_world_downsample(cvx_context *ctx, const void *storage, int64_t byteLength, int dimX, int dimY, int dimZ, int lod, int columnCount, int extraLods,
+                         void **outStorage, int64_t *outByteLength, int32_t *outColumnCount, int64_t *outVoxelCount, float *outDeviceMs);
+void cvx_free(void *p);
+
 /* Arithmetic self-test hook used by tests: evaluates op on n float pairs on
  * the device.  op: 0 a/b, 1 sqrt(a), 2 1/sqrt(a), 3 a*b+c style lerp a+b*(b-a),
  * 4 floor, 5 ceil, 6 round-half-even, 7 (int)a with the x86 rule. */

@@ -47,6 +47,12 @@ int cvxh_world_procedural(int dimX, int dimY, int dimZ, uint32_t seed, int threa
 /* WorldSaveFile.Deserialize / Serialize, WorldSaveFile.cs:57,8 */
 int cvxh_world_load(const char *path, cvxh_world_set **out);
 int cvxh_world_save(const cvxh_world_set *worlds, const char *path);
+/* Assemble a world set from storage blobs in the reference's layout, blob i = LOD i (what WorldSaveFile.Deserialize does
+ * per world, WorldSaveFile.cs:86-92; e.g. LOD 0 from the host build and LOD 1.. from cvx_world_downsample).  Copies. */
+int cvxh_world_from_blobs(int dimX, int dimY, int dimZ, int count, const void *const *blobs, const int64_t *byteLengths, cvxh_world_set **out);
+/* World.DownSample(extraLods) of LOD 0 on the host (World.cs:45), result discarded: returns the wall-clock seconds it took
+ * with `threads` worker threads (<= 0: all) -- the CPU side of the comparison with cvx_world_downsample. */
+int cvxh_world_downsample_seconds(const cvxh_world_set *worlds, int extraLods, int threads, double *outSeconds, int64_t *outVoxelCount);
 void cvxh_world_free(cvxh_world_set *worlds);
 int cvxh_world_lod_count(const cvxh_world_set *worlds);
 int cvxh_world_info_get(const cvxh_world_set *worlds, int lod, cvxh_world_info *out);

@@ -165,6 +165,43 @@ def test_blit_matches_pixel_centre_rule(contexts):
         assert (img == ref).all(), f"{name}: {(img != ref).sum()} screen pixels differ"
 
 
+@pytest.mark.parametrize("name", ["mill256", "proc256", "proc128x512x64"])
+def test_downsample_matches_host_build(contexts, name):
+    """cvx_world_downsample (World.DownSample on the device) against the host build of the same level: the storage blobs
+    (headers, guards, runs, averaged colours, element offsets) must be byte-identical for every LOD the reference builds."""
+    ws = scenes.load_world(name)
+    ctx = contexts(name, 320, 200)
+    for extra in range(1, ws.lod_count):
+        blob, columns, voxels, ms = ctx.downsample(ws, 0, extra)
+        want = ws.storage(extra)
+        info = ws.info(extra)
+        assert columns == info.columnCount, f"{name} LOD {extra}: ColumnCount {columns} vs {info.columnCount}"
+        got = np.frombuffer(blob, dtype=np.uint8)
+        assert got.size == want.size, f"{name} LOD {extra}: {got.size} bytes vs {want.size}"
+        diff = np.flatnonzero(got != want)
+        assert diff.size == 0, f"{name} LOD {extra}: first differing byte at {diff[0]} of {want.size} ({diff.size} differ)"
+        assert voxels > 0 and ms >= 0.0
+
+
+def test_world_with_device_built_lods_renders_identically(contexts):
+    """LOD 1..5 from cvx_world_downsample, assembled with cvxh_world_from_blobs, uploaded and rendered: same raybuffers as the
+    host-built chain (lodError 8 reaches the higher levels)."""
+    name = "proc256_t075_lod8"
+    ws, fr, W, H = scenes.scene_frame(name)
+    ctx = contexts(scenes.SCENES[name][0], W, H)
+    rebuilt = ctx.build_lods(ws)
+    assert rebuilt.lod_count == ws.lod_count
+    for lod in range(ws.lod_count):
+        assert np.array_equal(rebuilt.storage(lod), ws.storage(lod)), f"LOD {lod} blob differs"
+    ctx.upload_world(rebuilt)
+    try:
+        g_td, g_lr = _render_gpu(ctx, fr)
+        o_td, o_lr, _ = O.draw_segments(ws, fr, W, H, clear=CLEAR, counters=False)
+        _compare(name, fr, g_td, g_lr, o_td, o_lr)
+    finally:
+        ctx.upload_world(ws)
+
+
 def test_device_float_contract(contexts):
     """IEEE binary32 on the device: correctly rounded / and sqrt, no contraction, denormals kept, x86 (int) rule."""
     ctx = contexts("proc256", 320, 200)

@@ -219,3 +219,23 @@ def test_builder_rejects_bad_input():
         host.WorldSet.from_voxels((48, 64, 64), [], [], [], [])  # x not a power of two (WordBuilder.cs:30-32)
     with pytest.raises(RuntimeError):
         host.WorldSet.from_voxels((64, 64, 64), [64], [0], [0], [0xFFFFFFFF])  # voxel out of bounds
+
+
+def test_world_from_blobs_round_trip():
+    """cvxh_world_from_blobs: a set assembled from the storage blobs of another is the same world (WorldSaveFile.cs:86-92)."""
+    ws = scenes.load_world("proc64") if hasattr(scenes, "load_world") else None
+    blobs = [bytes(ws.storage(lod)) for lod in range(ws.lod_count)]
+    copy = host.WorldSet.from_blobs(ws.dims, blobs)
+    assert copy.lod_count == ws.lod_count and copy.dims == ws.dims
+    for lod in range(ws.lod_count):
+        a, b = ws.info(lod), copy.info(lod)
+        assert (a.columnCount, a.elementCount, a.byteLength, a.lod) == (b.columnCount, b.elementCount, b.byteLength, b.lod)
+        assert np.array_equal(ws.storage(lod), copy.storage(lod))
+    with pytest.raises(RuntimeError):
+        host.WorldSet.from_blobs(ws.dims, [b"\x00" * 16])
+
+
+def test_host_downsample_timing_hook():
+    ws = scenes.load_world("proc64")
+    seconds, voxels = ws.downsample_host_seconds(1, threads=2)
+    assert seconds >= 0.0 and voxels > 0
