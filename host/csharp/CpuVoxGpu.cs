@@ -54,6 +54,9 @@ namespace CpuVox.Gpu
 		[DllImport(Lib)] public static extern IntPtr cvx_last_error(IntPtr ctx);
 		[DllImport(Lib)] public static extern int cvx_set_stream(IntPtr ctx, IntPtr hipStream);
 		[DllImport(Lib)] public static extern int cvx_world_upload(IntPtr ctx, int lod, void* storage, long byteLength, int dimX, int dimY, int dimZ, int columnCount);
+		[DllImport(Lib)] public static extern int cvx_world_downsample(IntPtr ctx, void* storage, long byteLength, int dimX, int dimY, int dimZ, int lod, int columnCount, int extraLods,
+		                                                               out IntPtr outStorage, out long outByteLength, out int outColumnCount, out long outVoxelCount, out float outDeviceMs);
+		[DllImport(Lib)] public static extern void cvx_free(IntPtr p);
 		[DllImport(Lib)] public static extern int cvx_set_resolution(IntPtr ctx, int resolutionX, int resolutionY);
 		[DllImport(Lib)] public static extern int cvx_set_buffer_count(IntPtr ctx, int bufferCount);
 		[DllImport(Lib)] public static extern int cvx_draw_segments(IntPtr ctx, SegmentData* segments, CameraData* camera, int screenWidth, int screenHeight, float* vanishingPointScreenSpace, int bufferIndex, int flags);
@@ -96,6 +99,17 @@ namespace CpuVox.Gpu
 		public void UploadWorld(int lod, void* storageStartPointer, long byteLength, int dimX, int dimY, int dimZ, int columnCount)
 		{
 			Check(Native.cvx_world_upload(ctx, lod, storageStartPointer, byteLength, dimX, dimY, dimZ, columnCount));
+		}
+
+		/// <summary>World.DownSample(extraLods) (World.cs:45) on the GPU: returns the new level's storage blob (headers + elements, the
+		/// layout WorldSaveFile writes), to be wrapped exactly like WorldSaveFile.Deserialize wraps a file's world (WorldSaveFile.cs:86-92).
+		/// The caller copies it into its own allocation and calls <see cref="Native.cvx_free"/> on the pointer.</summary>
+		public IntPtr DownSample(void* storageStartPointer, long byteLength, int dimX, int dimY, int dimZ, int lod, int columnCount, int extraLods,
+		                         out long outByteLength, out int outColumnCount, out long outVoxelCount)
+		{
+			Check(Native.cvx_world_downsample(ctx, storageStartPointer, byteLength, dimX, dimY, dimZ, lod, columnCount, extraLods,
+			                                  out IntPtr blob, out outByteLength, out outColumnCount, out outVoxelCount, out float _));
+			return blob;
 		}
 
 		/// <summary>RenderManager.SetResolution (RenderManager.cs:94-109).</summary>
