@@ -42,6 +42,57 @@ int ParseFaceIndex(const std::string &line, size_t &index)
 
 bool StartsWith(const std::string &s, const char *p) { return s.compare(0, std::strlen(p), p) == 0; }
 
+std::string DirectoryOf(const std::string &path)
+{
+	const size_t slash = path.find_last_of("/\\");
+	return slash == std::string::npos ? std::string(".") : path.substr(0, slash);
+}
+
+// MaterialLib.ParseFromObj, SimpleMesh.cs:152-218: newmtl starts a material, map_Kd (with an optional "-bm <x>" prefix,
+// :187-196) loads its diffuse texture; every other statement is ignored like in the reference.
+bool ParseMaterialLib(const std::string &objPath, const std::string &relativeFilePath, std::vector<MeshMaterial> &materials, std::string *error)
+{
+	const std::string libPath = DirectoryOf(objPath) + "/" + relativeFilePath;
+	std::ifstream file(libPath);
+	if (!file) {
+		if (error) { *error = "cannot open mtllib " + libPath; }
+		return false;
+	}
+	materials.clear();
+	std::string line;
+	while (std::getline(file, line)) {
+		if (!line.empty() && line.back() == '\r') { line.pop_back(); }
+		if (line.empty() || line[0] == '#') { continue; }
+		if (StartsWith(line, "newmtl ")) {
+			MeshMaterial material;
+			material.MaterialIndex = (int)materials.size();
+			material.Name = line.substr(7);
+			materials.push_back(material);
+		} else if (StartsWith(line, "map_Kd ")) {
+			if (materials.empty()) {
+				if (error) { *error = libPath + ": map_Kd before newmtl"; }
+				return false;
+			}
+			size_t idx = 7;
+			if (idx + 2 < line.size() && line[idx] == '-' && line[idx + 1] == 'b' && line[idx + 2] == 'm') {
+				idx += 4;
+				while (idx < line.size() && line[idx] != ' ') { idx++; } // skip the -bm {x}
+				idx++;
+			}
+			if (idx >= line.size()) {
+				if (error) { *error = libPath + ": map_Kd without a path"; }
+				return false;
+			}
+			std::string relativeMapPath = line.substr(idx);
+			for (char &c : relativeMapPath) { if (c == '\\') { c = '/'; } }
+			if (!LoadImageFile(DirectoryOf(libPath) + "/" + relativeMapPath, materials.back().Diffuse, error)) {
+				return false;
+			}
+		}
+	}
+	return true;
+}
+
 } // namespace
 
 bool ImportObj(const std::string &path, bool swapYZ, SimpleMesh &mesh, std::string *error)
@@ -56,6 +107,8 @@ bool ImportObj(const std::string &path, bool swapYZ, SimpleMesh &mesh, std::stri
 	std::vector<float2> uvLookupTable;
 	mesh.Vertices.clear();
 	mesh.Indices.clear();
+	mesh.Materials.clear();
+	int activeMaterial = -1;
 
 	auto GatherVertex = [&](int positionIndex, int textureIndex) -> bool {
 		if (positionIndex < 0 || positionIndex >= (int)positionsLUT.size()) { return false; }
@@ -65,7 +118,7 @@ bool ImportObj(const std::string &path, bool swapYZ, SimpleMesh &mesh, std::stri
 		if (textureIndex >= 0 && textureIndex < (int)uvLookupTable.size()) {
 			vertex.UV = uvLookupTable[(size_t)textureIndex];
 		}
-		vertex.MaterialIndex = -1; // no mtllib support (mill.obj has none)
+		vertex.MaterialIndex = activeMaterial; // activeMaterial?.MaterialIndex ?? -1, ObjModel.cs:144
 		mesh.Vertices.push_back(vertex);
 		return true;
 	};
@@ -123,7 +176,22 @@ bool ImportObj(const std::string &path, bool swapYZ, SimpleMesh &mesh, std::stri
 				return false;
 			}
 		}
-		// vn / o / s / mtllib / usemtl: ignored (ObjModel.cs:43-51)
+		else if (StartsWith(line, "mtllib ")) { // ObjModel.cs:44-45
+			if (!ParseMaterialLib(path, line.substr(7), mesh.Materials, error)) {
+				return false;
+			}
+			activeMaterial = -1;
+		} else if (StartsWith(line, "usemtl ")) { // GetByName, :48-49 / SimpleMesh.cs:141-149; unknown names give "no material"
+			const std::string name = line.substr(7);
+			activeMaterial = -1;
+			for (const MeshMaterial &m : mesh.Materials) {
+				if (m.Name == name) {
+					activeMaterial = m.MaterialIndex;
+					break;
+				}
+			}
+		}
+		// vn / o / s: ignored (ObjModel.cs:42-47)
 	}
 	mesh.Indices.resize(mesh.Vertices.size());
 	for (size_t i = 0; i < mesh.Indices.size(); i++) { mesh.Indices[i] = (int)i; }
@@ -132,6 +200,21 @@ bool ImportObj(const std::string &path, bool swapYZ, SimpleMesh &mesh, std::stri
 		return false;
 	}
 	return true;
+}
+
+void MeshMaterial::GetDiffusePixel(float2 uv, float rgba[4]) const
+{
+	if (Diffuse.width <= 0 || Diffuse.height <= 0) {
+		rgba[0] = rgba[1] = rgba[2] = rgba[3] = 1.f;
+		return;
+	}
+	int px = (int)std::floor(uv.x * (float)(Diffuse.width - 1));
+	int py = (int)std::floor(uv.y * (float)(Diffuse.height - 1));
+	px = std::max(0, std::min(Diffuse.width - 1, px));
+	py = std::max(0, std::min(Diffuse.height - 1, py));
+	const uint8_t *p = &Diffuse.rgba[((size_t)px + (size_t)py * (size_t)Diffuse.width) * 4];
+	const float inv255 = 1.f / 255.f; // Color32 -> Color
+	for (int i = 0; i < 4; i++) { rgba[i] = p[i] * inv255; }
 }
 
 // Remap_Internal, SimpleMesh.cs:64-106
@@ -206,6 +289,7 @@ void VoxelizeTriangle(const SimpleMesh &mesh, int indexStart, WorldBuilder &buil
 	maxi.z = ClampI((int)std::ceil(maxf.z), 0, maxDimensions.z);
 
 	int written = 0;
+	const int materialIndex = (int)(int8_t)v0.MaterialIndex; // (sbyte)v0.MaterialIndex, VoxelizerHelper.cs:120
 	const float inv255 = 1.f / 255.f; // Color32 -> Color
 	float c0[3] = { v0.Color.r * inv255, v0.Color.g * inv255, v0.Color.b * inv255 };
 	float c1[3] = { v1.Color.r * inv255, v1.Color.g * inv255, v1.Color.b * inv255 };
@@ -235,12 +319,27 @@ void VoxelizeTriangle(const SimpleMesh &mesh, int indexStart, WorldBuilder &buil
 				if (bx < 0.f || by < 0.f || bz < 0.f || bx > 1.f || by > 1.f || bz > 1.f) {
 					continue;
 				}
-				ColorARGB32 color;
-				color.r = ToByte(c0[0] * bx + c1[0] * by + c2[0] * bz);
-				color.g = ToByte(c0[1] * bx + c1[1] * by + c2[1] * bz);
-				color.b = ToByte(c0[2] * bx + c1[2] * by + c2[2] * bz);
-				color.a = 255;
-				builder.SetVoxel(x, y, z, color);
+				float rgb[3] = { c0[0] * bx + c1[0] * by + c2[0] * bz, c0[1] * bx + c1[1] * by + c2[1] * bz, c0[2] * bx + c1[2] * by + c2[2] * bz };
+				bool keep = true;
+				if (materialIndex >= 0 && materialIndex < (int)mesh.Materials.size()) { // WordBuilder.cs:78-84
+					float2 uv;
+					uv.x = v0.UV.x * bx + v1.UV.x * by + v2.UV.x * bz;
+					uv.y = v0.UV.y * bx + v1.UV.y * by + v2.UV.y * bz;
+					float albedo[4];
+					mesh.Materials[(size_t)materialIndex].GetDiffusePixel(uv, albedo);
+					if (albedo[3] < 1.f) {
+						keep = false; // not fully opaque texels leave no voxel
+					}
+					for (int k = 0; k < 3; k++) { rgb[k] *= albedo[k]; }
+				}
+				if (keep) {
+					ColorARGB32 color;
+					color.r = ToByte(rgb[0]);
+					color.g = ToByte(rgb[1]);
+					color.b = ToByte(rgb[2]);
+					color.a = 255;
+					builder.SetVoxel(x, y, z, color);
+				}
 				if (++written == VOXELIZE_BUFFER_MAX) {
 					return; // buffer full, the triangle must have been huge (:124-126)
 				}
@@ -271,6 +370,11 @@ bool BuildWorldFromObj(const std::string &path, int maxDimension, bool swapYZ, b
 	}
 	try {
 		int3 worldDimensions = mesh.Rescale((float)maxDimension, float3(flipX ? -1.f : 1.f, flipY ? -1.f : 1.f, flipZ ? -1.f : 1.f));
+		if (worldDimensions.x <= 0 || worldDimensions.y <= 0 || worldDimensions.z <= 0) {
+			// Mathf.NextPowerOfTwo(0) == 0 (SimpleMesh.cs:78-80): a model without extent along an axis has no voxel grid
+			throw std::runtime_error("model has no extent along at least one axis at this max dimension (world dimensions " +
+			                         std::to_string(worldDimensions.x) + "x" + std::to_string(worldDimensions.y) + "x" + std::to_string(worldDimensions.z) + ")");
+		}
 		WorldBuilder builder(worldDimensions.x, worldDimensions.y, worldDimensions.z);
 		VoxelizeMesh(mesh, builder);
 		worlds.push_back(builder.ToLOD0World(lod0Voxels, threads));

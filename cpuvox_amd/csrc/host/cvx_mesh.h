@@ -1,14 +1,15 @@
 // cvx_mesh.h -- host-side OBJ import, rescale and triangle voxelizer: the
 // preprocessing that turns datasets/mill.obj into a world (configs 1-2).
 // Mirrors Assets/Code/Utils/ObjModel.cs, Utils/SimpleMesh.cs and
-// VoxelizerHelper.cs for the subset mill.obj uses (v x y z r g b / f a b c;
-// v/vt/vn index forms are parsed, materials and textures are not supported).
+// VoxelizerHelper.cs: v x y z [r g b] / vt / f a b c in all v/vt/vn index forms,
+// mtllib + usemtl with map_Kd diffuse textures (PNG, TGA, PPM: cvx_image.h).
 #pragma once
 
 #include <string>
 #include <vector>
 
 #include "cvx_host_math.h"
+#include "cvx_image.h"
 #include "cvx_world.h"
 
 namespace cvx {
@@ -25,10 +26,22 @@ struct MeshVertex {
 	int MaterialIndex;
 };
 
+// SimpleMesh.Material, SimpleMesh.cs:116-135
+struct MeshMaterial {
+	std::string Name;
+	int MaterialIndex = 0;
+	Image Diffuse; // map_Kd; empty when the material has none (the reference would throw on GetDiffusePixel then: treated as white here)
+
+	// GetDiffusePixel, SimpleMesh.cs:130-134: pixel = floor(uv * (size - 1)), no filtering.  The reference indexes the array
+	// unchecked (uv outside [0, 1] throws); the pixel is clamped into the texture here.  rgba in [0, 1] like UnityEngine.Color.
+	void GetDiffusePixel(float2 uv, float rgba[4]) const;
+};
+
 // SimpleMesh, SimpleMesh.cs:11-106 (indices are always 0..n-1, ObjModel.cs:164-167)
 struct SimpleMesh {
 	std::vector<MeshVertex> Vertices;
 	std::vector<int> Indices;
+	std::vector<MeshMaterial> Materials; // MaterialLib.Materials, SimpleMesh.cs:137-139
 
 	// SimpleMesh.Rescale -> Remap_Internal, SimpleMesh.cs:49-106
 	int3 Rescale(float maxDimension, float3 dimensionFlips);

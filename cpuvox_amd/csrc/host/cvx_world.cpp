@@ -219,17 +219,27 @@ void BuildColumns(World &target, int64_t count, int voxelScale, int16_t topY, in
 	for (int64_t base = 0; base < count; base += kBlock) {
 		int64_t n = std::min(kBlock, count - base);
 		int64_t blockTotal = 0;
+		std::string failure; // an exception must not leave the parallel region: the first one is re-thrown after it
 #pragma omp parallel num_threads(threads) reduction(+ : blockTotal)
 		{
 			RLEColumnBuilder builder;
 #pragma omp for schedule(dynamic, 256)
 			for (int64_t k = 0; k < n; k++) {
-				builder.Clear();
-				make(base + k, builder);
-				int64_t v = 0;
-				present[(size_t)k] = builder.ToFinalColumn(voxelScale, topY, block[(size_t)k], v) ? 1 : 0;
-				blockTotal += v;
+				try {
+					builder.Clear();
+					make(base + k, builder);
+					int64_t v = 0;
+					present[(size_t)k] = builder.ToFinalColumn(voxelScale, topY, block[(size_t)k], v) ? 1 : 0;
+					blockTotal += v;
+				} catch (const std::exception &e) {
+					present[(size_t)k] = 0;
+#pragma omp critical(cvx_build_columns_failure)
+					if (failure.empty()) { failure = e.what(); }
+				}
 			}
+		}
+		if (!failure.empty()) {
+			throw std::runtime_error(failure);
 		}
 		total += blockTotal;
 		for (int64_t k = 0; k < n; k++) {

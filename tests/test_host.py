@@ -239,3 +239,104 @@ def test_host_downsample_timing_hook():
     ws = scenes.load_world("proc64")
     seconds, voxels = ws.downsample_host_seconds(1, threads=2)
     assert seconds >= 0.0 and voxels > 0
+
+
+def _write_png(path, rgba):
+    """Minimal PNG writer (8-bit RGBA, filter 0) for the texture tests; rgba[y][x] with row 0 = TOP."""
+    import struct
+    import zlib
+
+    h, w = len(rgba), len(rgba[0])
+    raw = b"".join(b"\x00" + bytes(c for px in row for c in px) for row in rgba)
+
+    def chunk(kind, data):
+        return struct.pack(">I", len(data)) + kind + data + struct.pack(">I", zlib.crc32(kind + data) & 0xFFFFFFFF)
+
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b""))
+
+
+def _world_colours(ws):
+    """Set of (r, g, b) of every voxel of LOD 0 (colour entries of the element pool are bytes a, r, g, b)."""
+    info = ws.info(0)
+    blob = ws.storage(0)
+    hdr = blob[: info.columnCount * 12].view(np.dtype([("off", "<i4"), ("rc", "<u2"), ("mn", "<u2"), ("mx", "<u2"), ("pad", "<u2")]))
+    pool = blob[info.columnCount * 12:].view("<u4")
+    out, voxels = set(), 0
+    for h in hdr[hdr["rc"] > 0]:
+        runs = pool[h["off"] + 1: h["off"] + 1 + h["rc"]]
+        solid = [int(r >> 16) for r in runs if (int(r) & 0xFFFF) < 0x8000]
+        n = sum(solid)
+        voxels += n
+        for c in pool[h["off"] + h["rc"] + 2: h["off"] + h["rc"] + 2 + n]:
+            out.add(((int(c) >> 8) & 255, (int(c) >> 16) & 255, int(c) >> 24))
+    return out, voxels
+
+
+QUAD_OBJ = """mtllib quad.mtl
+v 0 0 0
+v 8 0 0
+v 8 4 8
+v 0 4 8
+vt 0 0
+vt 1 0
+vt 1 1
+vt 0 1
+usemtl painted
+f 1/1 2/2 3/3
+f 1/1 3/3 4/4
+"""
+
+
+def test_obj_material_textures(tmp_path):
+    """mtllib / usemtl / map_Kd (ObjModel.cs:44-49, SimpleMesh.cs:152-218, WordBuilder.cs:78-84): voxel colour = vertex colour * texel,
+    texels that are not fully opaque leave no voxel, PNG / TGA / PPM decode to the same world, JPEG is refused."""
+    # 3x3 texels, all different; GetDiffusePixel maps uv to floor(uv * (size - 1)), so texel column / row 2 is only hit at uv == 1
+    opaque = [[(40 * x + 10, 60 * y + 20, 200 - 30 * x, 255) for x in range(3)] for y in range(3)]  # rows top-down
+    palette = {px[:3] for row in opaque for px in row}
+    centre = opaque[1][1][:3]
+    (tmp_path / "quad.obj").write_text(QUAD_OBJ)
+    (tmp_path / "quad.mtl").write_text("# test\nnewmtl other\nKd 1 1 1\nnewmtl painted\nKd 0.5 0.5 0.5\nmap_Kd -bm 1.0 tex.png\n")
+    _write_png(tmp_path / "tex.png", opaque)
+    ws = host.WorldSet.from_obj(str(tmp_path / "quad.obj"), 8, flip=(False, False, False))
+    colours, voxels = _world_colours(ws)
+    assert colours <= palette and len(colours) >= 4 and centre in colours, colours
+    assert voxels >= 64
+
+    # the same picture as P6 PPM (rows top-down) builds the identical world
+    with open(tmp_path / "tex.ppm", "wb") as f:
+        f.write(b"P6\n# c\n3 3\n255\n" + bytes(c for row in opaque for px in row for c in px[:3]))
+    (tmp_path / "quad.mtl").write_text("newmtl painted\nmap_Kd tex.ppm\n")
+    ws_ppm = host.WorldSet.from_obj(str(tmp_path / "quad.obj"), 8, flip=(False, False, False))
+    assert np.array_equal(ws_ppm.storage(0), ws.storage(0))
+    # ... and as a bottom-up 32-bit TGA
+    with open(tmp_path / "tex.tga", "wb") as f:
+        f.write(bytes([0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 3, 0, 3, 0, 32, 8]) + bytes(c for row in opaque[::-1] for px in row for c in (px[2], px[1], px[0], px[3])))
+    (tmp_path / "quad.mtl").write_text("newmtl painted\nmap_Kd tex.tga\n")
+    ws_tga = host.WorldSet.from_obj(str(tmp_path / "quad.obj"), 8, flip=(False, False, False))
+    assert np.array_equal(ws_tga.storage(0), ws.storage(0))
+
+    # a translucent texel removes the voxels it covers
+    holed = [list(row) for row in opaque]
+    holed[1][1] = centre + (128,)
+    _write_png(tmp_path / "tex.png", holed)
+    (tmp_path / "quad.mtl").write_text("newmtl painted\nmap_Kd tex.png\n")
+    ws_holed = host.WorldSet.from_obj(str(tmp_path / "quad.obj"), 8, flip=(False, False, False))
+    colours_holed, voxels_holed = _world_colours(ws_holed)
+    assert voxels_holed < voxels and centre not in colours_holed
+
+    # unknown material name -> vertex colours only (white)
+    (tmp_path / "quad.obj").write_text(QUAD_OBJ.replace("usemtl painted", "usemtl missing"))
+    ws_plain = host.WorldSet.from_obj(str(tmp_path / "quad.obj"), 8, flip=(False, False, False))
+    assert _world_colours(ws_plain)[0] == {(255, 255, 255)}
+
+    # a degenerate (flat) model has a zero-height world: an error, not a crash
+    (tmp_path / "flat.obj").write_text("v 0 0 0\nv 8 0 0\nv 8 0 8\nf 1 2 3\n")
+    with pytest.raises(RuntimeError):
+        host.WorldSet.from_obj(str(tmp_path / "flat.obj"), 8, flip=(False, False, False))
+
+    (tmp_path / "quad.obj").write_text(QUAD_OBJ)
+    (tmp_path / "tex.jpg").write_bytes(b"\xff\xd8\xff\xe0" + b"\x00" * 32)
+    (tmp_path / "quad.mtl").write_text("newmtl painted\nmap_Kd tex.jpg\n")
+    with pytest.raises(RuntimeError, match="JPEG"):
+        host.WorldSet.from_obj(str(tmp_path / "quad.obj"), 8, flip=(False, False, False))
