@@ -254,7 +254,9 @@ def main():
         workload = f"{args.world} (mill.obj voxelised), {W}x{H}, benchmark-path poses, lodError {args.lod_error}"
 
     result = {
-        "metric": "Mrays/s, Phase-1 raybuffer rendering (DrawSegmentRayJob) at 1080p, 2048^3 world",
+        # BASELINE.json's metric on its configuration; other --width/--height/--world runs are labelled with what they ran
+        "metric": ("Mrays/s, Phase-1 raybuffer rendering (DrawSegmentRayJob) at 1080p, 2048^3 world" if (W, H, args.world) == (1920, 1080, "proc2048")
+                   else f"Mrays/s, Phase-1 raybuffer rendering (DrawSegmentRayJob) at {W}x{H}, {args.world} world"),
         "value": round(value, 3),
         "unit": "Mrays/s",
         "n_gpus": N,
