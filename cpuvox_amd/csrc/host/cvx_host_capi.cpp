@@ -47,6 +47,8 @@ cvx::Camera CameraFromPose(const cvxh_camera_pose &pose)
 extern "C" {
 
 const char *cvxh_last_error(void) { return g_error.c_str(); }
+int cvxh_default_threads(void) { return cvx::DefaultThreads(); }
+
 const char *cvxh_version(void) { return "cpuvox_host 0.1"; }
 
 int cvxh_world_from_obj(const char *path, int maxDimension, int swapYZ, int flipX, int flipY, int flipZ, int threads, cvxh_world_set **out)

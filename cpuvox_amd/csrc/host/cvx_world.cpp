@@ -14,6 +14,26 @@
 
 namespace cvx {
 
+// Worker threads for `threads <= 0`: OpenMP's default capped by the control group's CPU quota (cgroup v2 cpu.max): a
+// container usually sees every host CPU but may only use a few, and more runnable threads than that just take turns.
+int DefaultThreads()
+{
+#ifdef _OPENMP
+	int threads = omp_get_max_threads();
+	if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+		long long quota = 0, period = 0;
+		if (std::fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) {
+			const long long cpus = (quota + period - 1) / period;
+			if (cpus >= 1 && cpus < threads) { threads = (int)cpus; }
+		}
+		std::fclose(f);
+	}
+	return threads;
+#else
+	return 1;
+#endif
+}
+
 // ---------------------------------------------------------------------------
 // RLEColumnBuilder.ToFinalColumn, WordBuilder.cs:181-268
 // ---------------------------------------------------------------------------
@@ -212,7 +232,7 @@ void BuildColumns(World &target, int64_t count, int voxelScale, int16_t topY, in
 	std::vector<uint8_t> present(block.size());
 	int64_t total = 0;
 #ifdef _OPENMP
-	if (threads <= 0) { threads = omp_get_max_threads(); }
+	if (threads <= 0) { threads = DefaultThreads(); }
 #else
 	threads = 1;
 #endif
@@ -515,7 +535,7 @@ std::vector<World> BuildProceduralWorld(int dimX, int dimY, int dimZ, uint32_t s
 	c.height.resize((size_t)dimX * dimZ);
 	int maxDim = std::max(dimX, dimZ);
 #ifdef _OPENMP
-	if (threads <= 0) { threads = omp_get_max_threads(); }
+	if (threads <= 0) { threads = DefaultThreads(); }
 #endif
 #pragma omp parallel for schedule(static) num_threads(threads > 0 ? threads : 1)
 	for (int x = 0; x < dimX; x++) {

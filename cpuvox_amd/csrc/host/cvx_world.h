@@ -18,6 +18,8 @@
 
 namespace cvx {
 
+int DefaultThreads(); // worker threads used when a `threads` argument is <= 0 (cgroup-quota aware)
+
 constexpr int LOD_LEVELS = 6; // UnityManager.cs:42
 
 // Color24.cs:6-19: bytes a, r, g, b in memory order.

@@ -119,6 +119,11 @@ def lib() -> C.CDLL:
     return _lib
 
 
+def default_threads() -> int:
+    """Worker threads the host library uses for `threads <= 0` (cgroup-quota aware)."""
+    return lib().cvxh_default_threads()
+
+
 def _check(rc: int) -> None:
     if rc != 0:
         raise RuntimeError(f"cpuvox_host error {rc}: {lib().cvxh_last_error().decode()}")

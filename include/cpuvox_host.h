@@ -117,6 +117,10 @@ int cvxh_render_manager_read_raybuffer(cvxh_render_manager *rm, int which, int f
 /* BenchmarkPath.anim at clip time t in [0, 1.15], position scaled by world dims (UnityManager.cs:86-87). */
 void cvxh_sample_benchmark_path(float t, const float worldDims[3], float outPosition[3], float outEuler[3]);
 
+/* Worker threads the library starts when a `threads` argument is <= 0: the OpenMP default capped by the control group's
+ * CPU quota (cgroup v2 cpu.max). */
+int cvxh_default_threads(void);
+
 const char *cvxh_version(void);
 
 #ifdef __cplusplus

@@ -19,6 +19,7 @@
 
 #include <limits.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -944,10 +945,23 @@ static int trace_to_first_column_job(const ray_dda_context *inRays, const draw_c
 /* Mathf.RoundToInt = (int)Math.Round(f): half to even */
 static inline int round_to_int(float f) { return f2i(nearbyintf(f)); }
 
+/* Worker threads worth starting: OpenMP's default, capped by the CPU-time quota of the control group the process
+ * runs in (cgroup v2 cpu.max "quota period"; containers often see every host CPU but may only use a few of them,
+ * and more runnable threads than that just take turns). */
 int orc_max_threads(void)
 {
 #ifdef _OPENMP
-	return omp_get_max_threads();
+	int threads = omp_get_max_threads();
+	FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");
+	if (f) {
+		long long quota = 0, period = 0;
+		if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) {
+			long long cpus = (quota + period - 1) / period;
+			if (cpus >= 1 && cpus < threads) { threads = (int)cpus; }
+		}
+		fclose(f);
+	}
+	return threads;
 #else
 	return 1;
 #endif
@@ -969,7 +983,7 @@ int orc_draw_segments(const orc_segment_data segments[4],
 	}
 #ifdef _OPENMP
 	if (threads <= 0) {
-		threads = omp_get_max_threads();
+		threads = orc_max_threads();
 	}
 #else
 	threads = 1;

@@ -28,7 +28,7 @@ for extra in range(1, ws.lod_count):
     tot_dev += dev_ms / 1e3
     tot_wall += wall_s
     print(json.dumps({"lod": extra, "voxels": dev_voxels, "host_voxels": voxels, "identical_to_host_build": same, "host_s": round(host_s, 3),
-                      "host_threads": os.cpu_count(), "device_ms": round(dev_ms, 2), "call_s_incl_validation_pcie": round(wall_s, 3),
+                      "host_threads": host.default_threads(), "device_ms": round(dev_ms, 2), "call_s_incl_validation_pcie": round(wall_s, 3),
                       "source_GBps_device": round(src_bytes / (dev_ms / 1e3) / 1e9, 1), "out_bytes": len(blob)}))
 print(json.dumps({"world": f"proc{dim}", "lod0_bytes": src_bytes, "lod0_voxels": ws.lod0_voxels, "world_build_s_host": round(build_s, 1),
                   "downsample_1_5_host_s": round(tot_host, 2), "downsample_1_5_device_s": round(tot_dev, 3),
