@@ -1024,19 +1024,18 @@ int cvx_debug_section_cycles(cvx_context *ctx, uint64_t out[32], int reset)
 #endif
 }
 
-/* World.DownSample(extraLods), World.cs:45-127, on the device (cvx_downsample.h). */
-int cvx_world_downsample(cvx_context *ctx, const void *storage, int64_t byteLength, int dimX, int dimY, int dimZ, int lod, int columnCount, int extraLods,
-                         void **outStorage, int64_t *outByteLength, int32_t *outColumnCount, int64_t *outVoxelCount, float *outDeviceMs)
+namespace {
+
+// Validates a world blob (every column, like cvx_world_upload) and copies it to the device.
+int UploadSourceBlob(cvx_context *ctx, const void *storage, int64_t byteLength, int dimX, int dimY, int dimZ, int lod, int columnCount, uint8_t **dSrc)
 {
-	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
-	if (!storage || !outStorage || !outByteLength || !outColumnCount) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "bad arguments"); }
-	*outStorage = nullptr;
+	*dSrc = nullptr;
+	if (!storage) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "bad arguments"); }
 	if (!IsPow2(dimX) || !IsPow2(dimY) || !IsPow2(dimZ) || dimY > 65536) {
 		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "world dimensions must be powers of two (WordBuilder.cs:30), Y <= 65536");
 	}
-	const int targetLod = lod + extraLods;
-	if (lod < 0 || extraLods < 1 || targetLod > 15 || (dimX >> targetLod) < 1 || (dimY >> targetLod) < 1 || (dimZ >> targetLod) < 1 || extraLods > 8) {
-		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "lod %d + extraLods %d out of range for these dimensions", lod, extraLods);
+	if (lod < 0 || lod > 15 || (dimX >> lod) < 1 || (dimY >> lod) < 1 || (dimZ >> lod) < 1) {
+		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "lod %d out of range for these dimensions", lod);
 	}
 	const int64_t usedColumns = (int64_t)(dimX >> lod) * (dimZ >> lod);
 	if (columnCount < usedColumns || (int64_t)columnCount * 12 > byteLength) {
@@ -1051,21 +1050,38 @@ int cvx_world_downsample(cvx_context *ctx, const void *storage, int64_t byteLeng
 		const int rc = ValidateColumn(ctx, i, src[i], elements, elementCount, dimY >> lod, &solid);
 		if (rc != CVX_OK) { return rc; }
 	}
+	CVX_HIP(ctx, hipSetDevice(ctx->device));
+	CVX_HIP(ctx, hipMalloc((void **)dSrc, (size_t)byteLength));
+	hipError_t e = hipMemcpyAsync(*dSrc, storage, (size_t)byteLength, hipMemcpyHostToDevice, ctx->stream);
+	if (e != hipSuccess) {
+		(void)hipFree(*dSrc);
+		*dSrc = nullptr;
+		return Fail(ctx, CVX_ERR_HIP, "hipMemcpyAsync failed: %s", hipGetErrorString(e));
+	}
+	return CVX_OK;
+}
+
+// World.DownSample(extraLods) of the validated blob at dSrc (device); see cvx_world_downsample.
+int DownsampleDevice(cvx_context *ctx, const uint8_t *dSrc, int dimX, int dimY, int dimZ, int lod, int columnCount, int extraLods,
+                     void **outStorage, int64_t *outByteLength, int32_t *outColumnCount, int64_t *outVoxelCount, float *outDeviceMs)
+{
+	*outStorage = nullptr;
+	const int targetLod = lod + extraLods;
+	if (extraLods < 1 || extraLods > 8 || targetLod > 15 || (dimX >> targetLod) < 1 || (dimY >> targetLod) < 1 || (dimZ >> targetLod) < 1) {
+		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "lod %d + extraLods %d out of range for these dimensions", lod, extraLods);
+	}
 	const int64_t targetColumns = (int64_t)(dimX >> targetLod) * (dimZ >> targetLod);
 	const int64_t allocatedColumns = ((int64_t)dimX * dimZ) / ((int64_t)(targetLod + 1) * (targetLod + 1)); // World.ColumnCount, World.cs:17
 	if (targetColumns > 0x7FFFFFFF || allocatedColumns > 0x7FFFFFFF || allocatedColumns < targetColumns) {
 		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "target LOD has an unsupported column count");
 	}
 
-	CVX_HIP(ctx, hipSetDevice(ctx->device));
-	uint8_t *dSrc = nullptr;
 	uint32_t *dAlloc = nullptr, *dHeaders = nullptr, *dElements = nullptr;
 	unsigned long long *dScalars = nullptr; // [0] voxel count, [1] element total, [2] error flag
 	hipEvent_t evBegin = nullptr, evEnd = nullptr;
 	void *host = nullptr;
 	int rc = CVX_OK;
 	auto release = [&]() {
-		if (dSrc) { (void)hipFree(dSrc); }
 		if (dAlloc) { (void)hipFree(dAlloc); }
 		if (dHeaders) { (void)hipFree(dHeaders); }
 		if (dElements) { (void)hipFree(dElements); }
@@ -1084,13 +1100,11 @@ int cvx_world_downsample(cvx_context *ctx, const void *storage, int64_t byteLeng
 		}                                                                                                                 \
 	} while (0)
 	const size_t headerWords = (size_t)allocatedColumns * 3;
-	CVX_DS(hipMalloc((void **)&dSrc, (size_t)byteLength));
 	CVX_DS(hipMalloc((void **)&dAlloc, (size_t)targetColumns * 2 * sizeof(uint32_t)));
 	CVX_DS(hipMalloc((void **)&dHeaders, headerWords * sizeof(uint32_t)));
 	CVX_DS(hipMalloc((void **)&dScalars, 3 * sizeof(unsigned long long)));
 	CVX_DS(hipEventCreate(&evBegin));
 	CVX_DS(hipEventCreate(&evEnd));
-	CVX_DS(hipMemcpyAsync(dSrc, storage, (size_t)byteLength, hipMemcpyHostToDevice, ctx->stream));
 	CVX_DS(hipMemsetAsync(dHeaders, 0, headerWords * sizeof(uint32_t), ctx->stream));
 	CVX_DS(hipMemsetAsync(dScalars, 0, 3 * sizeof(unsigned long long), ctx->stream));
 
@@ -1153,6 +1167,51 @@ int cvx_world_downsample(cvx_context *ctx, const void *storage, int64_t byteLeng
 	*outColumnCount = (int32_t)allocatedColumns;
 	if (outVoxelCount) { *outVoxelCount = (int64_t)scalars[0]; }
 	if (outDeviceMs) { *outDeviceMs = ms; }
+	return CVX_OK;
+}
+
+} // namespace
+
+/* World.DownSample(extraLods), World.cs:45-127, on the device (cvx_downsample.h). */
+int cvx_world_downsample(cvx_context *ctx, const void *storage, int64_t byteLength, int dimX, int dimY, int dimZ, int lod, int columnCount, int extraLods,
+                         void **outStorage, int64_t *outByteLength, int32_t *outColumnCount, int64_t *outVoxelCount, float *outDeviceMs)
+{
+	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
+	if (!outStorage || !outByteLength || !outColumnCount) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "bad arguments"); }
+	*outStorage = nullptr;
+	uint8_t *dSrc = nullptr;
+	int rc = UploadSourceBlob(ctx, storage, byteLength, dimX, dimY, dimZ, lod, columnCount, &dSrc);
+	if (rc != CVX_OK) { return rc; }
+	rc = DownsampleDevice(ctx, dSrc, dimX, dimY, dimZ, lod, columnCount, extraLods, outStorage, outByteLength, outColumnCount, outVoxelCount, outDeviceMs);
+	(void)hipFree(dSrc);
+	return rc;
+}
+
+/* UnityManager.cs:328-331: worldLODs[i] = worldLODs[0].DownSample(i) for i = 1..levelCount, one validation + one upload of LOD 0. */
+int cvx_world_build_lods(cvx_context *ctx, const void *storage, int64_t byteLength, int dimX, int dimY, int dimZ, int columnCount, int levelCount,
+                         void **outStorage, int64_t *outByteLength, int32_t *outColumnCount, float *outDeviceMs)
+{
+	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
+	if (!outStorage || !outByteLength || !outColumnCount || levelCount < 1 || levelCount > 15) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "bad arguments"); }
+	for (int i = 0; i < levelCount; i++) { outStorage[i] = nullptr; }
+	uint8_t *dSrc = nullptr;
+	int rc = UploadSourceBlob(ctx, storage, byteLength, dimX, dimY, dimZ, 0, columnCount, &dSrc);
+	if (rc != CVX_OK) { return rc; }
+	float totalMs = 0.0f;
+	for (int i = 0; i < levelCount && rc == CVX_OK; i++) {
+		float ms = 0.0f;
+		rc = DownsampleDevice(ctx, dSrc, dimX, dimY, dimZ, 0, columnCount, i + 1, &outStorage[i], &outByteLength[i], &outColumnCount[i], nullptr, &ms);
+		totalMs += ms;
+	}
+	(void)hipFree(dSrc);
+	if (rc != CVX_OK) {
+		for (int i = 0; i < levelCount; i++) {
+			std::free(outStorage[i]);
+			outStorage[i] = nullptr;
+		}
+		return rc;
+	}
+	if (outDeviceMs) { *outDeviceMs = totalMs; }
 	return CVX_OK;
 }
 

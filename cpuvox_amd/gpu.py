@@ -29,7 +29,7 @@ EXPORTS = [
     "cvx_clear_raybuffer", "cvx_read_raybuffer", "cvx_blit_segments", "cvx_raybuffer_device_ptr",
     "cvx_screen_device_ptr", "cvx_last_draw_ms", "cvx_enable_counters", "cvx_get_counters",
     "cvx_get_raybuffer_layout", "cvx_selftest_math", "cvx_version", "cvx_bind_raybuffers", "cvx_draw_time_stats", "cvx_debug_section_cycles", "cvx_debug_occupancy", "cvx_copy_rows", "cvx_draw_segments_placed",
-    "cvx_world_downsample", "cvx_free",
+    "cvx_world_downsample", "cvx_world_build_lods", "cvx_free",
 ]
 
 
@@ -97,6 +97,8 @@ def lib() -> C.CDLL:
         L.cvx_selftest_math.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.cvx_world_downsample.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_float)]
+        L.cvx_world_build_lods.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_float)]
         L.cvx_free.argtypes = [C.c_void_p]
         L.cvx_free.restype = None
         _lib = L
@@ -162,9 +164,16 @@ class Context:
     def build_lods(self, world_set: WorldSet, levels: int = LOD_LEVELS) -> WorldSet:
         """UnityManager.cs:328-331 (`worldLODs[i] = worldLODs[0].DownSample(i)`) with the downsampling on the device:
         a new world set with LOD 0 taken from `world_set` and LOD 1..levels-1 built by cvx_world_downsample."""
-        blobs = [world_set.storage(0)]
-        for extra in range(1, levels):
-            blobs.append(self.downsample(world_set, 0, extra)[0])
+        i = world_set.info(0)
+        n = levels - 1
+        outs, sizes, columns, ms = (C.c_void_p * n)(), (C.c_int64 * n)(), (C.c_int32 * n)(), C.c_float()
+        self._check(lib().cvx_world_build_lods(self._h, i.storage, i.byteLength, i.dimX, i.dimY, i.dimZ, i.columnCount, n, outs, sizes, columns, C.byref(ms)))
+        try:
+            blobs = [world_set.storage(0)] + [C.string_at(outs[k], sizes[k]) for k in range(n)]
+        finally:
+            for k in range(n):
+                lib().cvx_free(outs[k])
+        self.last_build_lods_ms = ms.value
         return WorldSet.from_blobs(world_set.dims, blobs)
 
     def set_resolution(self, width: int, height: int) -> None:

@@ -56,6 +56,8 @@ namespace CpuVox.Gpu
 		[DllImport(Lib)] public static extern int cvx_world_upload(IntPtr ctx, int lod, void* storage, long byteLength, int dimX, int dimY, int dimZ, int columnCount);
 		[DllImport(Lib)] public static extern int cvx_world_downsample(IntPtr ctx, void* storage, long byteLength, int dimX, int dimY, int dimZ, int lod, int columnCount, int extraLods,
 		                                                               out IntPtr outStorage, out long outByteLength, out int outColumnCount, out long outVoxelCount, out float outDeviceMs);
+		[DllImport(Lib)] public static extern int cvx_world_build_lods(IntPtr ctx, void* storage, long byteLength, int dimX, int dimY, int dimZ, int columnCount, int levelCount,
+		                                                               IntPtr* outStorage, long* outByteLength, int* outColumnCount, out float outDeviceMs);
 		[DllImport(Lib)] public static extern void cvx_free(IntPtr p);
 		[DllImport(Lib)] public static extern int cvx_set_resolution(IntPtr ctx, int resolutionX, int resolutionY);
 		[DllImport(Lib)] public static extern int cvx_set_buffer_count(IntPtr ctx, int bufferCount);

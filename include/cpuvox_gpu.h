@@ -232,6 +232,11 @@ int cvx_debug_section_cycles(cvx_context *ctx, uint64_t out[32], int reset); /* 
  * and the offset scan. */
 int cvx_world_downsample(cvx_context *ctx, const void *storage, int64_t byteLength, int dimX, int dimY, int dimZ, int lod, int columnCount, int extraLods,
                          void **outStorage, int64_t *outByteLength, int32_t *outColumnCount, int64_t *outVoxelCount, float *outDeviceMs);
+/* UnityManager.cs:328-331 (`worldLODs[i] = worldLODs[0].DownSample(i)`): LOD 1..levelCount from the LOD 0 blob with one
+ * validation and one upload of it.  outStorage / outByteLength / outColumnCount are arrays of levelCount entries ([i] = LOD i+1);
+ * each blob is released with cvx_free.  outDeviceMs (may be NULL) = summed device time. */
+int cvx_world_build_lods(cvx_context *ctx, const void *storage, int64_t byteLength, int dimX, int dimY, int dimZ, int columnCount, int levelCount,
+                         void **outStorage, int64_t *outByteLength, int32_t *outColumnCount, float *outDeviceMs);
 void cvx_free(void *p);
 
 /* Arithmetic self-test hook used by tests: evaluates op on n float pairs on
