@@ -96,6 +96,8 @@ struct cvx_context {
 	int shardIndex = 0, shardCount = 1;
 	bool countersEnabled = false;
 	DevCounters *devCounters = nullptr;
+	int splitWaveBudget = 4096;                // DrawBatch cuts tiles into sub-tiles while the launch stays below this many waves
+	int forcedSplit = 0;                       // CVX_TILE_SPLIT=1|2|4|8 (diagnostics): fixed split factor
 };
 
 namespace {
@@ -457,6 +459,16 @@ int cvx_create(int device, cvx_context **out)
 	if ((e = hipStreamCreateWithFlags(&ctx->ownStream, hipStreamNonBlocking)) != hipSuccess) { return bail(e, "hipStreamCreate"); }
 	ctx->stream = ctx->ownStream;
 	if ((e = hipMalloc((void **)&ctx->devCounters, sizeof(DevCounters))) != hipSuccess) { return bail(e, "hipMalloc"); }
+	{
+		hipDeviceProp_t prop;
+		if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
+			ctx->splitWaveBudget = prop.multiProcessorCount * 16; // measured optimum on MI355X (256 CUs): at most ~4096 waves per launch
+		}
+		if (const char *v = std::getenv("CVX_TILE_SPLIT")) {
+			const int f = std::atoi(v);
+			if (f == 1 || f == 2 || f == 4 || f == 8) { ctx->forcedSplit = f; }
+		}
+	}
 	*out = ctx;
 	return CVX_OK;
 }
@@ -776,8 +788,28 @@ int DrawBatch(cvx_context *ctx, int frameCount, const cvx_segment_data *segments
 		}
 		const std::vector<float> &cost = ctx->hostTileCost;
 		std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
-		std::vector<DevTile> sorted(n);
-		for (size_t i = 0; i < n; i++) { sorted[i] = ctx->hostTiles[order[i]]; }
+		// Small batches (a single interactive frame is ~60 tiles on a chip with 1024 SIMDs): every tile is cut into 2, 4
+		// or 8 sub-tiles of consecutive rays, one wave each.  A wave's cost per column step is the union of what its rays
+		// need, so narrower waves finish sooner; with few waves there are idle SIMDs to run them on (1 frame: 6.7 -> 5.0 ms,
+		// 16 frames: 8.6 -> 6.3 ms).  Once the chip is full the fixed per-wave part dominates and splitting loses (256
+		// frames: x1.6 slower at split 2), hence the wave budget.
+		int split = 1;
+		while (split < 8 && n * (size_t)split * 2 <= (size_t)ctx->splitWaveBudget) { split *= 2; }
+		if (ctx->forcedSplit > 0) { split = ctx->forcedSplit; }
+		std::vector<DevTile> sorted;
+		sorted.reserve(n * (size_t)split);
+		const int lanesPerWave = CVX_WAVE / split;
+		for (size_t i = 0; i < n; i++) {
+			DevTile t = ctx->hostTiles[order[i]];
+			if (split == 1) {
+				sorted.push_back(t);
+				continue;
+			}
+			for (int k = 0; k < split; k++) {
+				t.lanes = (k * lanesPerWave) | (lanesPerWave << 8);
+				sorted.push_back(t);
+			}
+		}
 		ctx->hostTiles.swap(sorted);
 	}
 	return Launch(ctx, frameCount, flags);

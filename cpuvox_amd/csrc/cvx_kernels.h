@@ -787,9 +787,10 @@ __global__ __launch_bounds__(CVX_WAVE, 4) void render_kernel(const DevFrame *__r
 	}
 
 	// RaySetupJob (:19-39): tile -> (segment, planeRayIndex)
-	const int planeRayIndex = tile.tileInSeg * CVX_WAVE + lane;
-	const bool active = planeRayIndex < S.rayCount;
-	uint32_t *out = tile.out + lane;
+	const int firstLane = tile.lanes & 0xFF, laneCount = tile.lanes ? (tile.lanes >> 8) & 0xFF : CVX_WAVE;
+	const int planeRayIndex = tile.tileInSeg * CVX_WAVE + firstLane + lane;
+	const bool active = lane < laneCount && planeRayIndex < S.rayCount;
+	uint32_t *out = tile.out + firstLane + lane;
 	uint32_t *seen = lds + lane - wordBase * CVX_WAVE;
 	ProfLane prof;
 #ifdef CVX_PROFILE_SECTIONS
