@@ -97,7 +97,7 @@ struct cvx_context {
 	bool countersEnabled = false;
 	DevCounters *devCounters = nullptr;
 	int splitWaveBudget = 4096;                // DrawBatch cuts tiles into sub-tiles while the launch stays below this many waves
-	int forcedSplit = 0;                       // CVX_TILE_SPLIT=1|2|4|8 (diagnostics): fixed split factor
+	int forcedSplit = 0;                       // CVX_TILE_SPLIT=1|2|...|64 (diagnostics): fixed split factor
 };
 
 namespace {
@@ -466,7 +466,7 @@ int cvx_create(int device, cvx_context **out)
 		}
 		if (const char *v = std::getenv("CVX_TILE_SPLIT")) {
 			const int f = std::atoi(v);
-			if (f == 1 || f == 2 || f == 4 || f == 8) { ctx->forcedSplit = f; }
+			if (f >= 1 && f <= CVX_WAVE && (f & (f - 1)) == 0) { ctx->forcedSplit = f; }
 		}
 	}
 	*out = ctx;
@@ -788,13 +788,13 @@ int DrawBatch(cvx_context *ctx, int frameCount, const cvx_segment_data *segments
 		}
 		const std::vector<float> &cost = ctx->hostTileCost;
 		std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
-		// Small batches (a single interactive frame is ~60 tiles on a chip with 1024 SIMDs): every tile is cut into 2, 4
-		// or 8 sub-tiles of consecutive rays, one wave each.  A wave's cost per column step is the union of what its rays
-		// need, so narrower waves finish sooner; with few waves there are idle SIMDs to run them on (1 frame: 6.7 -> 5.0 ms,
-		// 16 frames: 8.6 -> 6.3 ms).  Once the chip is full the fixed per-wave part dominates and splitting loses (256
+		// Small batches (a single interactive frame is ~60 tiles on a chip with 1024 SIMDs): every tile is cut into 2, 4, ...
+		// 64 sub-tiles of consecutive rays, one wave each.  A wave's cost per column step is the union of what its rays
+		// need, so narrower waves finish sooner; with few waves there are idle SIMDs to run them on (1 frame: 6.7 -> 4.0 ms at
+		// 2 rays per wave, 16 frames: 8.6 -> 6.3 ms at 16).  Once the chip is full the fixed per-wave part dominates and splitting loses (256
 		// frames: x1.6 slower at split 2), hence the wave budget.
 		int split = 1;
-		while (split < 8 && n * (size_t)split * 2 <= (size_t)ctx->splitWaveBudget) { split *= 2; }
+		while (split < CVX_WAVE && n * (size_t)split * 2 <= (size_t)ctx->splitWaveBudget) { split *= 2; }
 		if (ctx->forcedSplit > 0) { split = ctx->forcedSplit; }
 		std::vector<DevTile> sorted;
 		sorted.reserve(n * (size_t)split);
