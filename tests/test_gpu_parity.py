@@ -202,6 +202,26 @@ def test_world_with_device_built_lods_renders_identically(contexts):
         ctx.upload_world(ws)
 
 
+@pytest.mark.parametrize("split", [1, 2, 16, 64])
+def test_sub_tile_split_is_invisible(split, monkeypatch):
+    """Small batches are rendered with tiles cut into sub-tiles of 64 / split rays per wave (DrawBatch); the raybuffers and the
+    counters must not depend on the cut (CVX_TILE_SPLIT pins the factor; the other tests run with the automatic choice)."""
+    monkeypatch.setenv("CVX_TILE_SPLIT", str(split))
+    ctx = gpu.Context(0)
+    try:
+        for name in ("mill256_t075", "proc256_t04_lod8"):
+            ws, fr, W, H = scenes.scene_frame(name)
+            ctx.upload_world(ws)
+            ctx.set_resolution(W, H)
+            g_td, g_lr = _render_gpu(ctx, fr, counters=True)
+            c = ctx.counters()
+            o_td, o_lr, oc = O.draw_segments(ws, fr, W, H, clear=CLEAR)
+            _compare(f"{name} split {split}", fr, g_td, g_lr, o_td, o_lr)
+            assert (c.S, c.E, c.C, c.P, c.R) == (oc.S, oc.E, oc.C, oc.P, oc.R)
+    finally:
+        ctx.close()
+
+
 def test_device_float_contract(contexts):
     """IEEE binary32 on the device: correctly rounded / and sqrt, no contraction, denormals kept, x86 (int) rule."""
     ctx = contexts("proc256", 320, 200)
