@@ -27,6 +27,9 @@ import os
 import sys
 import time
 
+# the host driver of the GPU boxes only supports dmabuf IPC: RCCL peer buffers need this before HIP initialises
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
