@@ -17,7 +17,7 @@
 
 namespace cvxk {
 
-#define CVX_DS_BUCKETS 2048 /* at most this many target-Y buckets are held in LDS per pass over the sources (48 KB) */
+#define CVX_DS_BUCKETS 256 /* target-Y buckets held in LDS per pass over the sources (6 KB); taller occupied spans take several passes */
 
 struct DownsampleParams {
 	const uint32_t *srcHeaders;  // 12-byte RLEColumn headers as 3 words each
@@ -78,8 +78,45 @@ __global__ __launch_bounds__(64) void downsample_kernel(DownsampleParams P, Down
 		}
 	};
 
-	for (int chunkTop = topY; chunkTop >= 0; chunkTop -= chunk) {
-		const int chunkLo = chunkTop - chunk + 1 > 0 ? chunkTop - chunk + 1 : 0;
+	// Only the buckets between the lowest and the highest voxel of the source columns can be occupied: everything above is
+	// one air run, everything below another.  (Found by walking the runs, not taken from the headers' WorldMin / WorldMax, so
+	// the result does not depend on those being consistent.)
+	int spanLo = 0x7FFFFFFF, spanHi = -1;
+	for (int s = lane; s < steps * steps; s += 64) {
+		const int x = xStart + (s / steps) * stepSize, z = zStart + (s % steps) * stepSize;
+		const uint32_t *h = P.srcHeaders + 3 * (size_t)((x >> P.srcLod) * P.srcMulX + (z >> P.srcLod));
+		const int runCount = (int)(h[1] & 0xFFFFu);
+		const uint32_t *guardStart = P.srcElements + h[0];
+		int elementBoundsX = srcHeight;
+		for (int run = 0; run < runCount; run++) {
+			const uint32_t raw = guardStart[run + 1];
+			const int length = (int)(int16_t)(raw >> 16);
+			elementBoundsX -= length;
+			if ((int16_t)(raw & 0xFFFFu) >= 0) {
+				spanHi = max(spanHi, (elementBoundsX + length - 1) >> P.extraLods);
+				spanLo = min(spanLo, elementBoundsX >> P.extraLods);
+			}
+		}
+	}
+	for (int o = 32; o > 0; o >>= 1) {
+		spanLo = min(spanLo, __shfl_xor(spanLo, o));
+		spanHi = max(spanHi, __shfl_xor(spanHi, o));
+	}
+	if (spanHi < 0) { // every source column is empty
+		if (!WRITE && lane == 0) {
+			O.alloc[k] = 0u;
+			O.runCounts[k] = 0u;
+		}
+		return;
+	}
+	if (spanHi > topY) { spanHi = topY; }
+	if (spanHi < topY) { // the air above the highest voxel
+		runSolid = false;
+		runLen = topY - spanHi;
+	}
+
+	for (int chunkTop = spanHi; chunkTop >= spanLo; chunkTop -= chunk) {
+		const int chunkLo = chunkTop - chunk + 1 > spanLo ? chunkTop - chunk + 1 : spanLo;
 		const int buckets = chunkTop - chunkLo + 1;
 		for (int b = lane; b < buckets; b += 64) {
 			sumR[b] = sumG[b] = sumB[b] = count[b] = 0u;
@@ -164,6 +201,13 @@ __global__ __launch_bounds__(64) void downsample_kernel(DownsampleParams P, Down
 			solid += __popcll(occupied);
 		}
 		__syncthreads();
+	}
+	if (spanLo > 0) { // the air below the lowest voxel
+		if (runLen > 0 && runSolid) {
+			flushRun();
+		}
+		runSolid = false;
+		runLen += spanLo;
 	}
 	flushRun();
 

@@ -1149,7 +1149,7 @@ int DownsampleDevice(cvx_context *ctx, const uint8_t *dSrc, int dimX, int dimY, 
 	P.srcMulX = dimZ >> lod;
 	P.targetColumnsZ = dimZ >> targetLod;
 	P.targetColumns = (int)targetColumns;
-	P.chunkBuckets = std::min(dimY >> targetLod, CVX_DS_BUCKETS);
+	P.chunkBuckets = std::min(dimY >> targetLod, CVX_DS_BUCKETS); // 6 KB of LDS: the wave count per CU, not LDS, limits residency
 	const size_t dsLdsBytes = (size_t)P.chunkBuckets * 24;
 	cvxk::DownsampleOut O{};
 	O.alloc = dAlloc;
