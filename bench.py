@@ -51,6 +51,8 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall time of the cpu_baseline sample at N = 1 (0 = skip)")
     ap.add_argument("--no-exchange", action="store_true", help="N > 1: skip the RCCL tile exchange (replica-style throughput)")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: finish each step's exchange before the next render")
+    ap.add_argument("--pmc-csv", default=None, help="counter summary of a rocprofv3 --pmc run of THIS command (tools/pmc_passes.sh + "
+                    "tools/pmc_aggregate.py): fills roofline.traffic from FETCH_SIZE + WRITE_SIZE; without it traffic is null")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' = single-GPU rehearsal of the N > 1 path "
                     "(all ranks share the visible GPUs, tiles travel through host memory)")
     return ap.parse_args()
@@ -298,6 +300,16 @@ def main():
             "column_visits_per_s": round(sum(visits[s] for s in steps) / k_sec, 1),
         },
     }
+
+    if args.pmc_csv:
+        # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB per dispatch (fabric requests of the L2, MI355X_MICROARCH.md "HBM"); raw sum:
+        # the guide's x2 correction holds for wide coalesced streams, this kernel's scattered 16/32-byte loads are uncalibrated.
+        import csv
+
+        with open(args.pmc_csv, newline="") as fh:
+            counters = {row["counter"]: float(row["mean_per_launch"]) for row in csv.DictReader(fh)}
+        result["roofline"]["traffic"] = int((counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024)
+        result["roofline"]["traffic_source"] = f"{os.path.basename(args.pmc_csv)}: FETCH_SIZE + WRITE_SIZE per launch, raw (uncorrected)"
 
     if N == 1:
         # Phase 2 (RenderManager.BlitSegments) over the frames of the last step, image left in HBM: reported beside
