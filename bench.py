@@ -301,6 +301,9 @@ def main():
         },
     }
 
+    committed_pmc = os.path.join(ROOT, "profiles", "r01_pmc_render_kernel.csv")
+    if not args.pmc_csv and N == 1 and (W, H, F, args.world, args.lod_error) == (1920, 1080, 512, "proc2048", 1.0) and os.path.exists(committed_pmc):
+        args.pmc_csv = committed_pmc  # the counter passes of exactly this command and kernel, collected with tools/pmc_passes.sh
     if args.pmc_csv:
         # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB per dispatch (fabric requests of the L2, MI355X_MICROARCH.md "HBM"); raw sum:
         # the guide's x2 correction holds for wide coalesced streams, this kernel's scattered 16/32-byte loads are uncalibrated.
@@ -309,7 +312,8 @@ def main():
         with open(args.pmc_csv, newline="") as fh:
             counters = {row["counter"]: float(row["mean_per_launch"]) for row in csv.DictReader(fh)}
         result["roofline"]["traffic"] = int((counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024)
-        result["roofline"]["traffic_source"] = f"{os.path.basename(args.pmc_csv)}: FETCH_SIZE + WRITE_SIZE per launch, raw (uncorrected)"
+        result["roofline"]["traffic_source"] = (f"{os.path.relpath(args.pmc_csv, ROOT)}: rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE per launch of this command "
+                                                "(separate counter passes, not this process), raw (uncorrected)")
 
     if N == 1:
         # Phase 2 (RenderManager.BlitSegments) over the frames of the last step, image left in HBM: reported beside
