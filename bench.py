@@ -309,11 +309,14 @@ def main():
         # the guide's x2 correction holds for wide coalesced streams, this kernel's scattered 16/32-byte loads are uncalibrated.
         import csv
 
-        with open(args.pmc_csv, newline="") as fh:
-            counters = {row["counter"]: float(row["mean_per_launch"]) for row in csv.DictReader(fh)}
-        result["roofline"]["traffic"] = int((counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024)
-        result["roofline"]["traffic_source"] = (f"{os.path.relpath(args.pmc_csv, ROOT)}: rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE per launch of this command "
-                                                "(separate counter passes, not this process), raw (uncorrected)")
+        try:
+            with open(args.pmc_csv, newline="") as fh:
+                counters = {row["counter"]: float(row["mean_per_launch"]) for row in csv.DictReader(fh)}
+            result["roofline"]["traffic"] = int((counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024)
+            result["roofline"]["traffic_source"] = (f"{os.path.relpath(args.pmc_csv, ROOT)}: rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE per launch of this command "
+                                                    "(separate counter passes, not this process), raw (uncorrected)")
+        except (OSError, KeyError, ValueError) as e:
+            result["roofline"]["traffic_source"] = f"unreadable counter summary {args.pmc_csv}: {e}"
 
     if N == 1:
         # Phase 2 (RenderManager.BlitSegments) over the frames of the last step, image left in HBM: reported beside
