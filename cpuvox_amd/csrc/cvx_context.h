@@ -1,0 +1,111 @@
+// cvx_context.h -- state and helpers shared by the translation units of libcpuvox_gpu.so (cvx_gpu.hip: context, raybuffers,
+// draw / read-back / blit; cvx_world.hip: world validation, upload, LOD construction).  Not part of the C ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "cpuvox_gpu.h"
+#include "cvx_device.h"
+
+struct RefHeader { // World.RLEColumn, World.cs:161-169
+	int32_t storageOffset;
+	uint16_t runCount;
+	uint16_t worldMin;
+	uint16_t worldMax;
+};
+static_assert(sizeof(RefHeader) == 12, "reference header is 12 bytes");
+
+struct LastDraw { // what read-back / blit need to know about a buffer pair
+	bool valid = false;
+	cvx_segment_data segments[4];
+	float vp[2];
+	int tileBase[4];
+	int width = 0, height = 0;
+};
+
+
+struct cvx_context {
+	int device = 0;
+	hipStream_t ownStream = nullptr;
+	hipStream_t stream = nullptr;
+	// one HIP event pair per draw since the last cvx_draw_time_stats(reset): kernel time on ctx->stream
+	std::vector<hipEvent_t> evPairs; // 2 * pairs
+	size_t evUsed = 0;               // pairs in use
+	double accumulatedMs = 0.0;      // folded-in pairs
+	int accumulatedDraws = 0;
+	float lastMs = 0.f;
+	std::string error;
+
+	// world
+	void *levelHeaders[CVX_LOD_LEVELS] = {};   // columnsDown, columnsUp, runsDown, runsUp: one allocation
+	void *levelElements[CVX_LOD_LEVELS] = {};
+	bool levelSet[CVX_LOD_LEVELS] = {};
+	DevWorld hostWorld{};
+	DevWorld *devWorld = nullptr;
+	bool worldDirty = true;
+
+	// raybuffers
+	int resX = 0, resY = 0;
+	int bufferCount = 2; // RenderManager.BUFFER_COUNT, RenderManager.cs:14
+	int tilesTD = 0, tilesLR = 0;
+	size_t poolBytesTD = 0, poolBytesLR = 0;
+	std::vector<uint32_t *> poolTD, poolLR; // per buffer: offsets into one allocation each
+	uint32_t *poolBaseTD = nullptr, *poolBaseLR = nullptr;
+	bool poolsExternal = false;
+	std::vector<LastDraw> last;
+	uint32_t *screen = nullptr;
+	uint32_t *staging = nullptr;
+	size_t stagingBytes = 0;
+
+	// per-draw scratch (grown on demand, reused)
+	DevFrame *devFrames = nullptr;
+	size_t devFramesCap = 0;
+	DevTile *devTiles = nullptr;
+	size_t devTilesCap = 0;
+	struct UploadSlot {
+		void *pinned = nullptr;
+		size_t bytes = 0;
+		hipEvent_t done = nullptr;
+		bool inFlight = false;
+	};
+	static constexpr int kUploadSlots = 3;
+	UploadSlot upload[kUploadSlots];
+	unsigned uploadNext = 0;
+	std::vector<DevFrame> hostFrames;
+	std::vector<DevTile> hostTiles;
+	std::vector<float> hostTileCost; // estimated DDA steps of the tile's middle ray (launch order: longest first)
+	std::vector<int> hostTileWords;  // LDS mask words per lane the tile needs
+	int maskWordsNeeded = 1;         // LDS mask words per lane the current launch needs (widest [origMin, origMax] window)
+
+	int shardIndex = 0, shardCount = 1;
+	bool countersEnabled = false;
+	DevCounters *devCounters = nullptr;
+	int splitWaveBudget = 4096;                // DrawBatch cuts tiles into sub-tiles while the launch stays below this many waves
+	int forcedSplit = 0;                       // CVX_TILE_SPLIT=1|2|...|64 (diagnostics): fixed split factor
+};
+
+namespace cvxi {
+
+// Records the message on the context (or for cvx_last_error(NULL) when ctx is null) and returns `code`.
+int Fail(cvx_context *ctx, int code, const char *fmt, ...) __attribute__((format(printf, 3, 4)));
+
+inline bool IsPow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+// One column of a world blob in the reference's layout (World.cs:161-209): element range inside the pool, both guards
+// present, positive run lengths that fit the column height, colours inside the pool.  Everything the kernels dereference
+// later is covered here.  *solidRuns receives the number of solid runs.
+int ValidateColumn(cvx_context *ctx, int64_t i, const RefHeader &h, const uint32_t *elements, int64_t elementCount, int maxY, size_t *solidRuns);
+
+} // namespace cvxi
+
+#define CVX_HIP(ctx, call)                                                                                              \
+	do {                                                                                                                \
+		hipError_t e_ = (call);                                                                                         \
+		if (e_ != hipSuccess) {                                                                                         \
+			return cvxi::Fail(ctx, CVX_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+		}                                                                                                               \
+	} while (0)

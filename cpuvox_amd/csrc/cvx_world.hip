@@ -1,0 +1,364 @@
+// cvx_world.hip -- libcpuvox_gpu.so, the world side of the C ABI: validation of the reference's storage blobs,
+// cvx_world_upload (blob -> device column records) and World.DownSample on the device (cvx_world_downsample,
+// cvx_world_build_lods; kernels in cvx_downsample.h).  See include/cpuvox_gpu.h for the contract of every entry point.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "cvx_context.h"
+#include "cvx_downsample.h"
+
+using cvxi::Fail;
+using cvxi::IsPow2;
+using cvxi::ValidateColumn;
+
+namespace cvxi {
+
+// One column of a world blob in the reference's layout (World.cs:161-209): element range inside the pool, both
+// guards present, positive run lengths that fit the column height, colours inside the pool.  Everything the kernels
+// dereference later is covered here.  *solidRuns receives the number of solid runs.
+int ValidateColumn(cvx_context *ctx, int64_t i, const RefHeader &h, const uint32_t *elements, int64_t elementCount, int maxY, size_t *solidRuns)
+{
+	const int64_t off = h.storageOffset;
+	if (off < 0 || off + h.runCount + 2 > elementCount) {
+		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "column %lld: element range outside the pool", (long long)i);
+	}
+	if (elements[off] != 0u || elements[off + h.runCount + 1] != 0u) {
+		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "column %lld: missing element guards (World.cs:205-209)", (long long)i);
+	}
+	int64_t colours = 0, total = 0;
+	size_t solid = 0;
+	for (int r = 0; r < h.runCount; r++) {
+		const uint32_t raw = elements[off + 1 + r];
+		const int colorsIndex = (int)(int16_t)(raw & 0xFFFFu);
+		const int length = (int)(int16_t)(raw >> 16);
+		if (length <= 0) {
+			return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "column %lld: run %d has length %d", (long long)i, r, length);
+		}
+		total += length;
+		if (colorsIndex >= 0) {
+			solid++;
+			if (colorsIndex + length > colours) { colours = colorsIndex + length; }
+		}
+	}
+	if (total > maxY || off + h.runCount + 2 + colours > elementCount) {
+		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "column %lld: runs exceed the world height or colours exceed the pool", (long long)i);
+	}
+	*solidRuns = solid;
+	return CVX_OK;
+}
+
+} // namespace cvxi
+
+int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byteLength, int dimX, int dimY, int dimZ, int columnCount)
+{
+	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
+	if (!storage || lod < 0 || lod >= CVX_LOD_LEVELS) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "bad storage / lod"); }
+	if (!IsPow2(dimX) || !IsPow2(dimY) || !IsPow2(dimZ) || dimY > 65536) {
+		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "world dimensions must be powers of two (WordBuilder.cs:30), Y <= 65536");
+	}
+	if (lod > 0 && (ctx->hostWorld.dimX != dimX || ctx->hostWorld.dimY != dimY || ctx->hostWorld.dimZ != dimZ) && ctx->levelSet[0]) {
+		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "all LODs share the LOD-0 dimensions (World.cs:47)");
+	}
+	const int64_t usedX = dimX >> lod, usedZ = dimZ >> lod;
+	const int64_t usedColumns = usedX * usedZ;
+	if (columnCount < usedColumns || (int64_t)columnCount * 12 > byteLength) {
+		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "columnCount %d inconsistent with dims/lod/byteLength", columnCount);
+	}
+	const int64_t elementCount = (byteLength - (int64_t)columnCount * 12) / 4;
+	const RefHeader *src = static_cast<const RefHeader *>(storage);
+	const uint32_t *elements = reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(storage) + (size_t)columnCount * 12);
+
+	// Validate every column (so that nothing the kernel dereferences can leave the pool) and build the two tables of
+	// 32-byte solid-run records plus the two overflow lists (cvx_device.h).
+	const size_t columnsAlloc = (size_t)(usedColumns > 0 ? usedColumns : 1);
+	const size_t tableEntries = columnsAlloc * 2;
+	const int maxY = dimY >> lod;
+	size_t overflowEntries = 2; // never empty: keeps the pointers valid
+	for (int64_t i = 0; i < usedColumns; i++) {
+		const RefHeader &h = src[i];
+		if (h.runCount == 0) {
+			continue;
+		}
+		size_t solid = 0;
+		const int rc = ValidateColumn(ctx, i, h, elements, elementCount, maxY, &solid);
+		if (rc != CVX_OK) {
+			return rc;
+		}
+		if (solid > 2) {
+			overflowEntries += (solid - 2 + 1) & ~(size_t)1; // lists start 16-byte aligned
+		}
+	}
+	std::vector<uint4> headers(tableEntries * 2, uint4{ 0u, 0u, 0u, 0u });
+	std::vector<uint2> overflow(overflowEntries * 2, uint2{ 0u, 0u }); // down list, then up list
+	size_t overflowCursor = 0;
+	std::vector<uint2> walk;
+	for (int64_t i = 0; i < usedColumns; i++) {
+		const RefHeader &h = src[i];
+		if (h.runCount == 0) {
+			continue;
+		}
+		const int64_t off = h.storageOffset;
+		const int n = h.runCount;
+		size_t solid = 0;
+		for (int r = 0; r < n; r++) {
+			solid += (int16_t)(elements[off + 1 + r] & 0xFFFFu) >= 0 ? 1u : 0u;
+		}
+		const size_t listBase = overflowCursor;
+		for (int dir = 0; dir < 2; dir++) { // 0: top-down (ITERATION_DIRECTION +1), 1: bottom-up
+			walk.clear();
+			uint32_t start = 0;
+			for (int k = 0; k < n; k++) {
+				const int r = dir == 0 ? k : n - 1 - k;
+				const uint32_t raw = elements[off + 1 + r];
+				const uint32_t length = raw >> 16;
+				if ((int16_t)(raw & 0xFFFFu) >= 0) {
+					walk.push_back(uint2{ start | (length << 16), (raw & 0xFFFFu) | ((uint32_t)(k + 1) << 16) });
+				}
+				start += length;
+			}
+			uint4 *rec = headers.data() + (dir == 0 ? 0 : tableEntries) + (size_t)i * 2;
+			rec[0] = uint4{ (uint32_t)(off + n + 2), (uint32_t)solid | ((uint32_t)h.worldMin << 16), (uint32_t)h.worldMax | ((uint32_t)n << 16), (uint32_t)listBase };
+			rec[1] = uint4{ solid > 0 ? walk[0].x : 0u, solid > 0 ? walk[0].y : 0u, solid > 1 ? walk[1].x : 0u, solid > 1 ? walk[1].y : 0u };
+			for (size_t k = 2; k < solid; k++) {
+				overflow[(dir == 0 ? 0 : overflowEntries) + listBase + (k - 2)] = walk[k];
+			}
+		}
+		if (solid > 2) {
+			overflowCursor += (solid - 2 + 1) & ~(size_t)1;
+		}
+	}
+
+	CVX_HIP(ctx, hipSetDevice(ctx->device));
+	CVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	if (ctx->levelHeaders[lod]) { (void)hipFree(ctx->levelHeaders[lod]); ctx->levelHeaders[lod] = nullptr; }
+	if (ctx->levelElements[lod]) { (void)hipFree(ctx->levelElements[lod]); ctx->levelElements[lod] = nullptr; }
+	ctx->levelSet[lod] = false;
+	const size_t headerBytes = headers.size() * sizeof(uint4);
+	CVX_HIP(ctx, hipMalloc(&ctx->levelHeaders[lod], headerBytes + overflow.size() * sizeof(uint2)));
+	const size_t kPoolPad = 4; // zeroed guard entries around the pool
+	CVX_HIP(ctx, hipMalloc(&ctx->levelElements[lod], ((size_t)(elementCount > 0 ? elementCount : 0) + 2 * kPoolPad) * 4));
+	CVX_HIP(ctx, hipMemset(ctx->levelElements[lod], 0, ((size_t)(elementCount > 0 ? elementCount : 0) + 2 * kPoolPad) * 4));
+	CVX_HIP(ctx, hipMemcpy(ctx->levelHeaders[lod], headers.data(), headerBytes, hipMemcpyHostToDevice));
+	CVX_HIP(ctx, hipMemcpy(static_cast<uint8_t *>(ctx->levelHeaders[lod]) + headerBytes, overflow.data(), overflow.size() * sizeof(uint2), hipMemcpyHostToDevice));
+	if (elementCount > 0) {
+		CVX_HIP(ctx, hipMemcpy(static_cast<uint32_t *>(ctx->levelElements[lod]) + kPoolPad, elements, (size_t)elementCount * 4, hipMemcpyHostToDevice));
+	}
+	DevWorldLevel &L = ctx->hostWorld.level[lod];
+	L.columnsDown = static_cast<const uint4 *>(ctx->levelHeaders[lod]);
+	L.columnsUp = L.columnsDown + tableEntries;
+	L.runsDown = reinterpret_cast<const uint2 *>(L.columnsDown + tableEntries * 2);
+	L.runsUp = L.runsDown + overflowEntries;
+	L.elements = static_cast<const uint32_t *>(ctx->levelElements[lod]) + kPoolPad;
+	L.shift = lod;
+	L.mulX = dimZ >> lod;
+	if (lod == 0) {
+		ctx->hostWorld.dimX = dimX;
+		ctx->hostWorld.dimY = dimY;
+		ctx->hostWorld.dimZ = dimZ;
+		ctx->hostWorld.maskX = dimX - 1;
+		ctx->hostWorld.maskZ = dimZ - 1;
+	}
+	ctx->levelSet[lod] = true;
+	ctx->worldDirty = true;
+	return CVX_OK;
+}
+
+namespace {
+
+// Validates a world blob (every column, like cvx_world_upload) and copies it to the device.
+int UploadSourceBlob(cvx_context *ctx, const void *storage, int64_t byteLength, int dimX, int dimY, int dimZ, int lod, int columnCount, uint8_t **dSrc)
+{
+	*dSrc = nullptr;
+	if (!storage) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "bad arguments"); }
+	if (!IsPow2(dimX) || !IsPow2(dimY) || !IsPow2(dimZ) || dimY > 65536) {
+		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "world dimensions must be powers of two (WordBuilder.cs:30), Y <= 65536");
+	}
+	if (lod < 0 || lod > 15 || (dimX >> lod) < 1 || (dimY >> lod) < 1 || (dimZ >> lod) < 1) {
+		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "lod %d out of range for these dimensions", lod);
+	}
+	const int64_t usedColumns = (int64_t)(dimX >> lod) * (dimZ >> lod);
+	if (columnCount < usedColumns || (int64_t)columnCount * 12 > byteLength) {
+		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "columnCount %d inconsistent with dims/lod/byteLength", columnCount);
+	}
+	const int64_t elementCount = (byteLength - (int64_t)columnCount * 12) / 4;
+	const RefHeader *src = static_cast<const RefHeader *>(storage);
+	const uint32_t *elements = reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(storage) + (size_t)columnCount * 12);
+	for (int64_t i = 0; i < usedColumns; i++) {
+		if (src[i].runCount == 0) { continue; }
+		size_t solid = 0;
+		const int rc = ValidateColumn(ctx, i, src[i], elements, elementCount, dimY >> lod, &solid);
+		if (rc != CVX_OK) { return rc; }
+	}
+	CVX_HIP(ctx, hipSetDevice(ctx->device));
+	CVX_HIP(ctx, hipMalloc((void **)dSrc, (size_t)byteLength));
+	hipError_t e = hipMemcpyAsync(*dSrc, storage, (size_t)byteLength, hipMemcpyHostToDevice, ctx->stream);
+	if (e != hipSuccess) {
+		(void)hipFree(*dSrc);
+		*dSrc = nullptr;
+		return Fail(ctx, CVX_ERR_HIP, "hipMemcpyAsync failed: %s", hipGetErrorString(e));
+	}
+	return CVX_OK;
+}
+
+// World.DownSample(extraLods) of the validated blob at dSrc (device); see cvx_world_downsample.
+int DownsampleDevice(cvx_context *ctx, const uint8_t *dSrc, int dimX, int dimY, int dimZ, int lod, int columnCount, int extraLods,
+                     void **outStorage, int64_t *outByteLength, int32_t *outColumnCount, int64_t *outVoxelCount, float *outDeviceMs)
+{
+	*outStorage = nullptr;
+	const int targetLod = lod + extraLods;
+	if (extraLods < 1 || extraLods > 8 || targetLod > 15 || (dimX >> targetLod) < 1 || (dimY >> targetLod) < 1 || (dimZ >> targetLod) < 1) {
+		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "lod %d + extraLods %d out of range for these dimensions", lod, extraLods);
+	}
+	const int64_t targetColumns = (int64_t)(dimX >> targetLod) * (dimZ >> targetLod);
+	const int64_t allocatedColumns = ((int64_t)dimX * dimZ) / ((int64_t)(targetLod + 1) * (targetLod + 1)); // World.ColumnCount, World.cs:17
+	if (targetColumns > 0x7FFFFFFF || allocatedColumns > 0x7FFFFFFF || allocatedColumns < targetColumns) {
+		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "target LOD has an unsupported column count");
+	}
+
+	uint32_t *dAlloc = nullptr, *dHeaders = nullptr, *dElements = nullptr;
+	unsigned long long *dScalars = nullptr; // [0] voxel count, [1] element total, [2] error flag
+	hipEvent_t evBegin = nullptr, evEnd = nullptr;
+	void *host = nullptr;
+	int rc = CVX_OK;
+	auto release = [&]() {
+		if (dAlloc) { (void)hipFree(dAlloc); }
+		if (dHeaders) { (void)hipFree(dHeaders); }
+		if (dElements) { (void)hipFree(dElements); }
+		if (dScalars) { (void)hipFree(dScalars); }
+		if (evBegin) { (void)hipEventDestroy(evBegin); }
+		if (evEnd) { (void)hipEventDestroy(evEnd); }
+	};
+#define CVX_DS(call)                                                                                                      \
+	do {                                                                                                                  \
+		hipError_t e_ = (call);                                                                                           \
+		if (e_ != hipSuccess) {                                                                                           \
+			rc = Fail(ctx, CVX_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__);       \
+			release();                                                                                                    \
+			std::free(host);                                                                                              \
+			return rc;                                                                                                    \
+		}                                                                                                                 \
+	} while (0)
+	const size_t headerWords = (size_t)allocatedColumns * 3;
+	CVX_DS(hipMalloc((void **)&dAlloc, (size_t)targetColumns * 2 * sizeof(uint32_t)));
+	CVX_DS(hipMalloc((void **)&dHeaders, headerWords * sizeof(uint32_t)));
+	CVX_DS(hipMalloc((void **)&dScalars, 3 * sizeof(unsigned long long)));
+	CVX_DS(hipEventCreate(&evBegin));
+	CVX_DS(hipEventCreate(&evEnd));
+	CVX_DS(hipMemsetAsync(dHeaders, 0, headerWords * sizeof(uint32_t), ctx->stream));
+	CVX_DS(hipMemsetAsync(dScalars, 0, 3 * sizeof(unsigned long long), ctx->stream));
+
+	cvxk::DownsampleParams P{};
+	P.srcHeaders = reinterpret_cast<const uint32_t *>(dSrc);
+	P.srcElements = reinterpret_cast<const uint32_t *>(dSrc + (size_t)columnCount * 12);
+	P.srcLod = lod;
+	P.extraLods = extraLods;
+	P.dimY = dimY;
+	P.srcMulX = dimZ >> lod;
+	P.targetColumnsZ = dimZ >> targetLod;
+	P.targetColumns = (int)targetColumns;
+	P.chunkBuckets = std::min(dimY >> targetLod, CVX_DS_BUCKETS); // 6 KB of LDS: the wave count per CU, not LDS, limits residency
+	const size_t dsLdsBytes = (size_t)P.chunkBuckets * 24;
+	cvxk::DownsampleOut O{};
+	O.alloc = dAlloc;
+	O.runCounts = dAlloc + targetColumns;
+	O.headers = dHeaders;
+	O.voxelCount = dScalars;
+	O.error = reinterpret_cast<int *>(dScalars + 2);
+
+	CVX_DS(hipEventRecord(evBegin, ctx->stream));
+	hipLaunchKernelGGL((cvxk::downsample_kernel<false>), dim3((unsigned)targetColumns), dim3(64), dsLdsBytes, ctx->stream, P, O);
+	hipLaunchKernelGGL(cvxk::exclusive_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, dAlloc, (int)targetColumns, dScalars + 1);
+	CVX_DS(hipGetLastError());
+	unsigned long long scalars[3] = { 0, 0, 0 };
+	CVX_DS(hipMemcpyAsync(scalars, dScalars, sizeof scalars, hipMemcpyDeviceToHost, ctx->stream));
+	CVX_DS(hipStreamSynchronize(ctx->stream));
+	if ((int)scalars[2] != 0) {
+		release();
+		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "a downsampled column needs more than 65535 runs (World.cs:193-195)");
+	}
+	if (scalars[1] > 0x7FFFFFFFull) {
+		release();
+		return Fail(ctx, CVX_ERR_CAPACITY, "Only supports up to 2^31 elements (World.cs:355-357)");
+	}
+	const size_t elementTotal = (size_t)scalars[1];
+	CVX_DS(hipMalloc((void **)&dElements, (elementTotal > 0 ? elementTotal : 1) * sizeof(uint32_t)));
+	O.elements = dElements;
+	hipLaunchKernelGGL((cvxk::downsample_kernel<true>), dim3((unsigned)targetColumns), dim3(64), dsLdsBytes, ctx->stream, P, O);
+	CVX_DS(hipGetLastError());
+	CVX_DS(hipEventRecord(evEnd, ctx->stream));
+	const size_t outBytes = headerWords * 4 + elementTotal * 4;
+	host = std::malloc(outBytes > 0 ? outBytes : 1);
+	if (!host) {
+		release();
+		return Fail(ctx, CVX_ERR_HIP, "out of host memory");
+	}
+	CVX_DS(hipMemcpyAsync(host, dHeaders, headerWords * 4, hipMemcpyDeviceToHost, ctx->stream));
+	if (elementTotal > 0) {
+		CVX_DS(hipMemcpyAsync(static_cast<uint8_t *>(host) + headerWords * 4, dElements, elementTotal * 4, hipMemcpyDeviceToHost, ctx->stream));
+	}
+	CVX_DS(hipStreamSynchronize(ctx->stream));
+	float ms = 0.0f;
+	CVX_DS(hipEventElapsedTime(&ms, evBegin, evEnd));
+#undef CVX_DS
+	release();
+	*outStorage = host;
+	*outByteLength = (int64_t)outBytes;
+	*outColumnCount = (int32_t)allocatedColumns;
+	if (outVoxelCount) { *outVoxelCount = (int64_t)scalars[0]; }
+	if (outDeviceMs) { *outDeviceMs = ms; }
+	return CVX_OK;
+}
+
+} // namespace
+
+/* World.DownSample(extraLods), World.cs:45-127, on the device (cvx_downsample.h). */
+int cvx_world_downsample(cvx_context *ctx, const void *storage, int64_t byteLength, int dimX, int dimY, int dimZ, int lod, int columnCount, int extraLods,
+                         void **outStorage, int64_t *outByteLength, int32_t *outColumnCount, int64_t *outVoxelCount, float *outDeviceMs)
+{
+	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
+	if (!outStorage || !outByteLength || !outColumnCount) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "bad arguments"); }
+	*outStorage = nullptr;
+	uint8_t *dSrc = nullptr;
+	int rc = UploadSourceBlob(ctx, storage, byteLength, dimX, dimY, dimZ, lod, columnCount, &dSrc);
+	if (rc != CVX_OK) { return rc; }
+	rc = DownsampleDevice(ctx, dSrc, dimX, dimY, dimZ, lod, columnCount, extraLods, outStorage, outByteLength, outColumnCount, outVoxelCount, outDeviceMs);
+	(void)hipFree(dSrc);
+	return rc;
+}
+
+/* UnityManager.cs:328-331: worldLODs[i] = worldLODs[0].DownSample(i) for i = 1..levelCount, one validation + one upload of LOD 0. */
+int cvx_world_build_lods(cvx_context *ctx, const void *storage, int64_t byteLength, int dimX, int dimY, int dimZ, int columnCount, int levelCount,
+                         void **outStorage, int64_t *outByteLength, int32_t *outColumnCount, float *outDeviceMs)
+{
+	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
+	if (!outStorage || !outByteLength || !outColumnCount || levelCount < 1 || levelCount > 15) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "bad arguments"); }
+	for (int i = 0; i < levelCount; i++) { outStorage[i] = nullptr; }
+	uint8_t *dSrc = nullptr;
+	int rc = UploadSourceBlob(ctx, storage, byteLength, dimX, dimY, dimZ, 0, columnCount, &dSrc);
+	if (rc != CVX_OK) { return rc; }
+	float totalMs = 0.0f;
+	for (int i = 0; i < levelCount && rc == CVX_OK; i++) {
+		float ms = 0.0f;
+		rc = DownsampleDevice(ctx, dSrc, dimX, dimY, dimZ, 0, columnCount, i + 1, &outStorage[i], &outByteLength[i], &outColumnCount[i], nullptr, &ms);
+		totalMs += ms;
+	}
+	(void)hipFree(dSrc);
+	if (rc != CVX_OK) {
+		for (int i = 0; i < levelCount; i++) {
+			std::free(outStorage[i]);
+			outStorage[i] = nullptr;
+		}
+		return rc;
+	}
+	if (outDeviceMs) { *outDeviceMs = totalMs; }
+	return CVX_OK;
+}
+
+void cvx_free(void *p)
+{
+	std::free(p);
+}
