@@ -165,7 +165,7 @@ def test_blit_matches_pixel_centre_rule(contexts):
         assert (img == ref).all(), f"{name}: {(img != ref).sum()} screen pixels differ"
 
 
-@pytest.mark.parametrize("name", ["mill256", "proc256", "proc128x512x64"])
+@pytest.mark.parametrize("name", ["mill256", "proc256", "proc128x512x64", "proc64x4096x32"])  # the last: occupied spans taller than one LDS chunk
 def test_downsample_matches_host_build(contexts, name):
     """cvx_world_downsample (World.DownSample on the device) against the host build of the same level: the storage blobs
     (headers, guards, runs, averaged colours, element offsets) must be byte-identical for every LOD the reference builds."""
