@@ -252,7 +252,13 @@ inline int ClampI(int v, int lo, int hi) { return std::max(lo, std::min(hi, v));
 
 // VoxelizerHelper.GetVoxelsInternal, VoxelizerHelper.cs:28-132, writing
 // straight into the builder columns (WordBuilder.cs:76-88, no materials).
-void VoxelizeTriangle(const SimpleMesh &mesh, int indexStart, WorldBuilder &builder)
+struct EmittedVoxel { // VoxelizerHelper.VoxelizedPosition after the material step (WordBuilder.cs:76-88)
+	int32_t x, z;
+	int16_t y;
+	ColorARGB32 color;
+};
+
+void VoxelizeTriangle(const SimpleMesh &mesh, int indexStart, int3 dims, std::vector<EmittedVoxel> &out)
 {
 	const MeshVertex &v0 = mesh.Vertices[(size_t)mesh.Indices[(size_t)indexStart]];
 	const MeshVertex &v1 = mesh.Vertices[(size_t)mesh.Indices[(size_t)indexStart + 1]];
@@ -278,7 +284,6 @@ void VoxelizeTriangle(const SimpleMesh &mesh, int indexStart, WorldBuilder &buil
 
 	float3 minf = min3(a, min3(b, c));
 	float3 maxf = max3(a, max3(b, c));
-	int3 dims = builder.Dimensions();
 	int3 maxDimensions; maxDimensions.x = dims.x - 1; maxDimensions.y = dims.y - 1; maxDimensions.z = dims.z - 1;
 	int3 mini, maxi;
 	mini.x = ClampI((int)std::floor(minf.x), 0, maxDimensions.x);
@@ -338,7 +343,7 @@ void VoxelizeTriangle(const SimpleMesh &mesh, int indexStart, WorldBuilder &buil
 					color.g = ToByte(rgb[1]);
 					color.b = ToByte(rgb[2]);
 					color.a = 255;
-					builder.SetVoxel(x, y, z, color);
+					out.push_back({ x, z, (int16_t)y, color });
 				}
 				if (++written == VOXELIZE_BUFFER_MAX) {
 					return; // buffer full, the triangle must have been huge (:124-126)
@@ -350,13 +355,30 @@ void VoxelizeTriangle(const SimpleMesh &mesh, int indexStart, WorldBuilder &buil
 
 } // namespace
 
-void VoxelizeMesh(const SimpleMesh &mesh, WorldBuilder &builder)
+void VoxelizeMesh(const SimpleMesh &mesh, WorldBuilder &builder, int threads)
 {
-	// The reference splits triangles over Environment.ProcessorCount tasks and
-	// appends under a per-column lock; the result is order independent (sort +
-	// average in ToFinalColumn), so a sequential loop gives the same world.
-	for (size_t i = 0; i + 2 < mesh.Indices.size(); i += 3) {
-		VoxelizeTriangle(mesh, (int)i, builder);
+	// The reference splits the triangles over Environment.ProcessorCount tasks that append to the columns under a lock
+	// (WordBuilder.cs:44-95).  The finished world does not depend on the order of insertion (ToFinalColumn sorts by Y and
+	// averages voxels that share one), so here every thread voxelises its triangles into a private list and the lists are
+	// appended to the columns one thread at a time.
+	const int64_t triangles = (int64_t)(mesh.Indices.size() / 3);
+	const int3 dims = builder.Dimensions();
+#ifdef _OPENMP
+	if (threads <= 0) { threads = DefaultThreads(); }
+#else
+	threads = 1;
+#endif
+#pragma omp parallel num_threads(threads)
+	{
+		std::vector<EmittedVoxel> local;
+#pragma omp for schedule(dynamic, 64) nowait
+		for (int64_t t = 0; t < triangles; t++) {
+			VoxelizeTriangle(mesh, (int)(t * 3), dims, local);
+		}
+#pragma omp critical(cvx_voxelize_merge)
+		for (const EmittedVoxel &v : local) {
+			builder.SetVoxel(v.x, v.y, v.z, v.color);
+		}
 	}
 }
 
@@ -376,7 +398,7 @@ bool BuildWorldFromObj(const std::string &path, int maxDimension, bool swapYZ, b
 			                         std::to_string(worldDimensions.x) + "x" + std::to_string(worldDimensions.y) + "x" + std::to_string(worldDimensions.z) + ")");
 		}
 		WorldBuilder builder(worldDimensions.x, worldDimensions.y, worldDimensions.z);
-		VoxelizeMesh(mesh, builder);
+		VoxelizeMesh(mesh, builder, threads);
 		worlds.push_back(builder.ToLOD0World(lod0Voxels, threads));
 		for (int j = 1; j < LOD_LEVELS; j++) {
 			worlds.push_back(worlds[0].DownSample(j, nullptr, threads));

@@ -52,7 +52,7 @@ bool ImportObj(const std::string &path, bool swapYZ, SimpleMesh &mesh, std::stri
 
 // WorldBuilder.Import (WordBuilder.cs:39-97) on top of VoxelizerHelper.GetVoxelsInternal
 // (VoxelizerHelper.cs:28-132).
-void VoxelizeMesh(const SimpleMesh &mesh, WorldBuilder &builder);
+void VoxelizeMesh(const SimpleMesh &mesh, WorldBuilder &builder, int threads = 0);
 
 // UnityManager "Convert" (UnityManager.cs:297-343): import, rescale (X flipped
 // by default, UnityManager.cs:27), voxelize, LOD0 + 5 down-sampled levels.
