@@ -40,7 +40,7 @@ struct DownsampleOut {
 };
 
 template <bool WRITE>
-__global__ __launch_bounds__(64) void downsample_kernel(DownsampleParams P, DownsampleOut O)
+__global__ __launch_bounds__(256) void downsample_kernel(DownsampleParams P, DownsampleOut O)
 {
 	// dynamic LDS: `chunk` = min(target height, CVX_DS_BUCKETS) buckets of 24 bytes (the launch passes chunk * 24)
 	extern __shared__ unsigned long long dsLds[];
@@ -48,7 +48,12 @@ __global__ __launch_bounds__(64) void downsample_kernel(DownsampleParams P, Down
 	unsigned long long *first = dsLds;
 	uint32_t *sumR = reinterpret_cast<uint32_t *>(dsLds + chunk), *sumG = sumR + chunk, *sumB = sumG + chunk, *count = sumB + chunk;
 
-	const int lane = threadIdx.x;
+	// 64 threads per target column for low LODs, 256 for high ones (1024 source columns per target column at LOD 5): all of them
+	// gather the sources, the first wave alone writes the column
+	const int thread = threadIdx.x, threads = blockDim.x;
+	const int lane = thread & 63;
+	const bool emitter = thread < 64;
+	__shared__ int spanShared[8];
 	const int k = blockIdx.x;
 	const int targetLod = P.srcLod + P.extraLods;
 	const int step = 1 << targetLod, stepSize = 1 << P.srcLod, steps = 1 << P.extraLods;
@@ -82,7 +87,7 @@ __global__ __launch_bounds__(64) void downsample_kernel(DownsampleParams P, Down
 	// one air run, everything below another.  (Found by walking the runs, not taken from the headers' WorldMin / WorldMax, so
 	// the result does not depend on those being consistent.)
 	int spanLo = 0x7FFFFFFF, spanHi = -1;
-	for (int s = lane; s < steps * steps; s += 64) {
+	for (int s = thread; s < steps * steps; s += threads) {
 		const int x = xStart + (s / steps) * stepSize, z = zStart + (s % steps) * stepSize;
 		const uint32_t *h = P.srcHeaders + 3 * (size_t)((x >> P.srcLod) * P.srcMulX + (z >> P.srcLod));
 		const int runCount = (int)(h[1] & 0xFFFFu);
@@ -102,8 +107,19 @@ __global__ __launch_bounds__(64) void downsample_kernel(DownsampleParams P, Down
 		spanLo = min(spanLo, __shfl_xor(spanLo, o));
 		spanHi = max(spanHi, __shfl_xor(spanHi, o));
 	}
+	if (threads > 64) { // combine the waves of the block
+		if (lane == 0) {
+			spanShared[2 * (thread >> 6)] = spanLo;
+			spanShared[2 * (thread >> 6) + 1] = spanHi;
+		}
+		__syncthreads();
+		for (int w = 0; w < (threads >> 6); w++) {
+			spanLo = min(spanLo, spanShared[2 * w]);
+			spanHi = max(spanHi, spanShared[2 * w + 1]);
+		}
+	}
 	if (spanHi < 0) { // every source column is empty
-		if (!WRITE && lane == 0) {
+		if (!WRITE && thread == 0) {
 			O.alloc[k] = 0u;
 			O.runCounts[k] = 0u;
 		}
@@ -118,14 +134,14 @@ __global__ __launch_bounds__(64) void downsample_kernel(DownsampleParams P, Down
 	for (int chunkTop = spanHi; chunkTop >= spanLo; chunkTop -= chunk) {
 		const int chunkLo = chunkTop - chunk + 1 > spanLo ? chunkTop - chunk + 1 : spanLo;
 		const int buckets = chunkTop - chunkLo + 1;
-		for (int b = lane; b < buckets; b += 64) {
+		for (int b = thread; b < buckets; b += threads) {
 			sumR[b] = sumG[b] = sumB[b] = count[b] = 0u;
 			first[b] = ~0ull;
 		}
 		__syncthreads();
 
 		// DownSamplePartial for source column s = ix * steps + iz (the reference's insertion order, World.cs:85-94)
-		for (int s = lane; s < steps * steps; s += 64) {
+		for (int s = thread; s < steps * steps; s += threads) {
 			const int x = xStart + (s / steps) * stepSize, z = zStart + (s % steps) * stepSize;
 			const uint32_t *h = P.srcHeaders + 3 * (size_t)((x >> P.srcLod) * P.srcMulX + (z >> P.srcLod));
 			const uint32_t offset = h[0];
@@ -164,8 +180,8 @@ __global__ __launch_bounds__(64) void downsample_kernel(DownsampleParams P, Down
 		}
 		__syncthreads();
 
-		// ToFinalColumn over this chunk, top-down, 64 buckets per step (lane 0 = highest Y)
-		for (int g = chunkTop; g >= chunkLo; g -= 64) {
+		// ToFinalColumn over this chunk, top-down, 64 buckets per step (lane 0 = highest Y), first wave only
+		for (int g = chunkTop; emitter && g >= chunkLo; g -= 64) {
 			const int y = g - lane;
 			const bool valid = y >= chunkLo;
 			const uint32_t n = valid ? count[y - chunkLo] : 0u;
@@ -201,6 +217,9 @@ __global__ __launch_bounds__(64) void downsample_kernel(DownsampleParams P, Down
 			solid += __popcll(occupied);
 		}
 		__syncthreads();
+	}
+	if (!emitter) {
+		return; // the run / colour state lives in the first wave
 	}
 	if (spanLo > 0) { // the air below the lowest voxel
 		if (runLen > 0 && runSolid) {

@@ -262,6 +262,7 @@ int DownsampleDevice(cvx_context *ctx, const uint8_t *dSrc, int dimX, int dimY, 
 	P.targetColumns = (int)targetColumns;
 	P.chunkBuckets = std::min(dimY >> targetLod, CVX_DS_BUCKETS); // 6 KB of LDS: the wave count per CU, not LDS, limits residency
 	const size_t dsLdsBytes = (size_t)P.chunkBuckets * 24;
+	const unsigned dsThreads = extraLods >= 3 ? 256u : 64u; // (2^extraLods)^2 source columns per target column
 	cvxk::DownsampleOut O{};
 	O.alloc = dAlloc;
 	O.runCounts = dAlloc + targetColumns;
@@ -270,7 +271,7 @@ int DownsampleDevice(cvx_context *ctx, const uint8_t *dSrc, int dimX, int dimY, 
 	O.error = reinterpret_cast<int *>(dScalars + 2);
 
 	CVX_DS(hipEventRecord(evBegin, ctx->stream));
-	hipLaunchKernelGGL((cvxk::downsample_kernel<false>), dim3((unsigned)targetColumns), dim3(64), dsLdsBytes, ctx->stream, P, O);
+	hipLaunchKernelGGL((cvxk::downsample_kernel<false>), dim3((unsigned)targetColumns), dim3(dsThreads), dsLdsBytes, ctx->stream, P, O);
 	hipLaunchKernelGGL(cvxk::exclusive_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, dAlloc, (int)targetColumns, dScalars + 1);
 	CVX_DS(hipGetLastError());
 	unsigned long long scalars[3] = { 0, 0, 0 };
@@ -287,7 +288,7 @@ int DownsampleDevice(cvx_context *ctx, const uint8_t *dSrc, int dimX, int dimY, 
 	const size_t elementTotal = (size_t)scalars[1];
 	CVX_DS(hipMalloc((void **)&dElements, (elementTotal > 0 ? elementTotal : 1) * sizeof(uint32_t)));
 	O.elements = dElements;
-	hipLaunchKernelGGL((cvxk::downsample_kernel<true>), dim3((unsigned)targetColumns), dim3(64), dsLdsBytes, ctx->stream, P, O);
+	hipLaunchKernelGGL((cvxk::downsample_kernel<true>), dim3((unsigned)targetColumns), dim3(dsThreads), dsLdsBytes, ctx->stream, P, O);
 	CVX_DS(hipGetLastError());
 	CVX_DS(hipEventRecord(evEnd, ctx->stream));
 	const size_t outBytes = headerWords * 4 + elementTotal * 4;
