@@ -3,6 +3,8 @@
 
 #include <cstring>
 #include <exception>
+#include <dlfcn.h>
+
 #include <chrono>
 #include <memory>
 #include <string>
@@ -229,10 +231,21 @@ struct cvxh_render_manager {
 
 int cvxh_render_manager_create(int device, int screenWidth, int screenHeight, const char *gpuLibraryPath, cvxh_render_manager **out)
 {
-	if (!out || !gpuLibraryPath) { return Fail("bad argument"); }
+	if (!out) { return Fail("bad argument"); }
 	try {
+		std::string path = gpuLibraryPath ? gpuLibraryPath : "";
+		if (path.empty()) { // default: libcpuvox_gpu.so in the directory this library was loaded from
+			Dl_info self{};
+			if (dladdr(reinterpret_cast<const void *>(&cvxh_render_manager_create), &self) && self.dli_fname) {
+				path = self.dli_fname;
+				const size_t slash = path.find_last_of('/');
+				path = (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/libcpuvox_gpu.so";
+			} else {
+				path = "libcpuvox_gpu.so";
+			}
+		}
 		auto h = std::make_unique<cvxh_render_manager>();
-		h->rm = std::make_unique<cvx::RenderManager>(device, screenWidth, screenHeight, gpuLibraryPath);
+		h->rm = std::make_unique<cvx::RenderManager>(device, screenWidth, screenHeight, path);
 		*out = h.release();
 	} catch (const std::exception &e) {
 		return Fail(e.what());

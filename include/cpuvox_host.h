@@ -98,7 +98,7 @@ int cvxh_setup_frame(const cvxh_camera_pose *pose, int limitHorizon, float farCl
 /*
  * RenderManager twin (Assets/Code/RenderManager.cs:12-256): SetResolution :94, SwapBuffers :53, ClearRayBuffer :58,
  * DrawWorld :111 (vanishing point + segments + CameraData on the host, DrawSegments and BlitSegments on the GPU
- * through libcpuvox_gpu.so, loaded from gpuLibraryPath).  Fails (no CPU fallback) when the library or a HIP device
+ * through libcpuvox_gpu.so, loaded from gpuLibraryPath; NULL = the file of that name next to libcpuvox_host.so).  Fails (no CPU fallback) when the library or a HIP device
  * is missing.  renderMode: 0 ScreenBuffer, 1 RayBufferTopDown, 2 RayBufferLeftRight (UnityManager.ERenderMode).
  */
 typedef struct cvxh_render_manager cvxh_render_manager;

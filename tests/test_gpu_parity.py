@@ -222,6 +222,35 @@ def test_sub_tile_split_is_invisible(split, monkeypatch):
         ctx.close()
 
 
+def test_cpp_example_on_the_c_abis(tmp_path):
+    """examples/flythrough.cpp: world building, camera, the RenderManager twin and the GPU library used from plain C++ through
+    the two C ABIs (no Python in the loop); the image it writes for path key t = 0 equals the Python-driven render of the same pose."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "cpuvox_amd", "csrc"), "examples"], stdout=subprocess.DEVNULL)
+    W, H = 320, 200
+    prefix = str(tmp_path / "fly")
+    out = subprocess.run([os.path.join(root, "cpuvox_amd", "flythrough"), "proc:128", "3", str(W), str(H), prefix],
+                         check=True, capture_output=True, text=True, timeout=300).stdout
+    assert "3 frames at 320x200" in out and "fps" in out, out
+    with open(prefix + "_0.ppm", "rb") as f:
+        assert f.readline() == b"P6\n" and f.readline() == b"320 200\n" and f.readline() == b"255\n"
+        rgb = np.frombuffer(f.read(), dtype=np.uint8).reshape(H, W, 3)
+    from cpuvox_amd import host
+    from cpuvox_amd.render_manager import RenderManager
+
+    ws = host.WorldSet.procedural(128, 128, 128)
+    rm = RenderManager(W, H)
+    rm.upload_world(ws)
+    pos, eul = host.sample_benchmark_path(0.0, ws.dims)
+    lods, far = host.setup_lods(host.camera_pose(pos, eul, W, H), ws.max_dimension, W, H, 1.0)
+    rm.swap_buffers()
+    img = rm.draw_world(host.camera_pose(pos, eul, W, H), lods, far)
+    want = np.stack([(img >> 8) & 255, (img >> 16) & 255, img >> 24], axis=-1).astype(np.uint8)[::-1]
+    assert np.array_equal(rgb, want)
+
+
 def test_device_float_contract(contexts):
     """IEEE binary32 on the device: correctly rounded / and sqrt, no contraction, denormals kept, x86 (int) rule."""
     ctx = contexts("proc256", 320, 200)
