@@ -22,6 +22,26 @@
 
 namespace cvxk {
 
+// World tables, element pools and raybuffer tiles are reached through pointers that the kernel reads from memory
+// (DevWorld / DevTile), so the compiler cannot tell that they are global and emits FLAT loads and stores -- and a flat
+// access may come back out of order, so every wait on one is s_waitcnt vmcnt(0) lgkmcnt(0): the look-ahead fetch of the
+// next column's record would be waited for by the first colour load or run-list load of the current column.  Saying
+// "global" (address space 1) gives global_load / global_store, which return in order and can be waited for with counted
+// vmcnt(N), leaving the younger look-ahead loads in flight.
+#ifndef CVX_EXP_FLAT
+#define CVX_GLOBAL __attribute__((address_space(1)))
+#else
+#define CVX_GLOBAL
+#endif
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4))); // (HIP's uint4 / uint2 classes cannot be copied out of a qualified address space)
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef const CVX_GLOBAL u32x4 *gptr_u4;
+typedef const CVX_GLOBAL u32x2 *gptr_u2;
+typedef const CVX_GLOBAL uint32_t *gptr_u32;
+typedef CVX_GLOBAL uint32_t *gptr_out;
+__device__ __forceinline__ uint4 ld4(gptr_u4 p) { const u32x4 v = *p; return uint4{ v.x, v.y, v.z, v.w }; }
+__device__ __forceinline__ uint2 ld2(gptr_u2 p) { const u32x2 v = *p; return uint2{ v.x, v.y }; }
+
 // ---- Unity.Mathematics scalar semantics (math.cs 1.2.6) --------------------
 __device__ __forceinline__ float m_min(float x, float y) { return (y != y || x < y) ? x : y; }
 __device__ __forceinline__ float m_max(float x, float y) { return (y != y || x > y) ? x : y; }
@@ -301,7 +321,7 @@ struct LaneCounters {
 // ---------------------------------------------------------------------------
 template <int DIR, bool COUNT>
 __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S, const DevWorld *__restrict__ world, int planeRayIndex,
-                                          uint32_t *seen /* &lds[lane] */, uint32_t *out /* tile + lane */, LaneCounters &cnt, ProfLane &prof)
+                                          uint32_t *seen /* &lds[lane] */, gptr_out out /* tile + lane */, LaneCounters &cnt, ProfLane &prof)
 {
 	(void)prof;
 	const int omin = S.omin, omax = S.omax;
@@ -381,8 +401,8 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 	uint4 header, queue;              // record of the current column: header + its first two solid runs in walk order
 	float curDistLast, curDistNext;   // ray.IntersectionDistances of the current column
 	int curScale;                     // voxelScale of the current column
-	const uint32_t *curElements;      // element pool of the current column's LOD (colours)
-	const uint2 *curRuns;             // overflow list (solid runs 2..) of the current column's LOD and walk direction
+	gptr_u32 curElements;             // element pool of the current column's LOD (colours)
+	gptr_u2 curRuns;                  // overflow list (solid runs 2..) of the current column's LOD and walk direction
 	unsigned int consumed = 0u;       // counting variant: elements the reference's walk has dereferenced in this column
 	float worldBoundsMin, worldBoundsMax;
 
@@ -392,10 +412,10 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		const int solidCount = (int)(header.y & 0xFFFFu);
 		CVX_BEGIN();
 		if (COUNT) { consumed = 0u; }
-		const uint2 *overflowRuns = curRuns + header.w - 2; // solid run k >= 2 lives at overflowRuns[k]
+		const gptr_u2 overflowRuns = curRuns + header.w - 2; // solid run k >= 2 lives at overflowRuns[k]
 		uint4 ext = { 0u, 0u, 0u, 0u };
 		if (solidCount > 2) {
-			ext = *reinterpret_cast<const uint4 *>(overflowRuns + 2); // runs 2 and 3; issued now, the latency hides behind the clip / first run
+			ext = ld4((gptr_u4)(overflowRuns + 2)); // runs 2 and 3; issued now, the latency hides behind the clip / first run
 		}
 		// :289-293
 		const f3 camSpaceMinLast = f3_madd(planeStartBottom, planeDir, curDistLast);
@@ -463,7 +483,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		// bounds the reference accumulates are exactly these integers), so only solid runs are iterated here.
 		float elementBoundsMin, elementBoundsMax;
 		int solidIndex = 0;
-		const uint32_t *worldColumnColors = curElements + header.x; // ColorPointer, World.cs:185
+		const gptr_u32 worldColumnColors = curElements + header.x; // ColorPointer, World.cs:185
 
 		// Element loop :441-611, realigned for SIMT: every lane first walks its own elements (cheap: decode,
 		// bounds bookkeeping, air / world-bounds culls :445-475) up to its next run that has to be projected;
@@ -483,7 +503,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 					w0 = odd ? pair.z : pair.x;
 					w1 = odd ? pair.w : pair.y;
 				} else {
-					const uint2 run = overflowRuns[solidIndex];
+					const uint2 run = ld2(overflowRuns + solidIndex);
 					w0 = run.x;
 					w1 = run.y;
 				}
@@ -664,7 +684,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		return true;
 	};
 
-	const uint4 *table = DIR > 0 ? L.columnsDown : L.columnsUp;
+	gptr_u4 table = (gptr_u4)(DIR > 0 ? L.columnsDown : L.columnsUp);
 
 	// column 0: LOD check (:237-243), bounds test and fetch (World.GetVoxelColumn, World.cs:130-142)
 	if (ray.distLast >= lodMax && lod < 5) {
@@ -672,7 +692,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		lod++;
 		voxelScale *= 2;
 		L = world->level[lod];
-		table = DIR > 0 ? L.columnsDown : L.columnsUp;
+		table = (gptr_u4)(DIR > 0 ? L.columnsDown : L.columnsUp);
 		lodMax = F.lod[lod];
 	}
 	if ((ray.px & maskX) != ray.px || (ray.pz & maskZ) != ray.pz) {
@@ -680,9 +700,9 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 	}
 	{
 		const size_t column = (size_t)((ray.px >> L.shift) * L.mulX + (ray.pz >> L.shift));
-		const uint4 *rec = table + 2 * column;
-		header = rec[0];
-		queue = rec[1];
+		const gptr_u4 rec = table + 2 * column;
+		header = ld4(rec);
+		queue = ld4(rec + 1);
 	}
 
 	while (true) {
@@ -696,8 +716,8 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		curDistLast = ray.distLast;
 		curDistNext = ray.distNext;
 		curScale = voxelScale;
-		curElements = L.elements;
-		curRuns = DIR > 0 ? L.runsDown : L.runsUp;
+		curElements = (gptr_u32)L.elements;
+		curRuns = (gptr_u2)(DIR > 0 ? L.runsDown : L.runsUp);
 		const int curLod = lod;
 		const bool lastColumn = dda_step(ray, farClip); // true: far clip reached after this column
 		// (the LOD check and the fetch are done for every lane, also one that stops after this column: its state is
@@ -707,14 +727,14 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			lod++;
 			voxelScale *= 2;
 			L = world->level[lod];
-			table = DIR > 0 ? L.columnsDown : L.columnsUp;
+			table = (gptr_u4)(DIR > 0 ? L.columnsDown : L.columnsUp);
 			lodMax = F.lod[lod];
 		}
 		const bool nextOutside = (ray.px & maskX) != ray.px || (ray.pz & maskZ) != ray.pz;
 		const size_t column = (size_t)(((ray.px & maskX) >> L.shift) * L.mulX + ((ray.pz & maskZ) >> L.shift)); // clamped into the table
-		const uint4 *rec = table + 2 * column;
-		const uint4 nextHeader = rec[0];
-		const uint4 nextQueue = rec[1];
+		const gptr_u4 rec = table + 2 * column;
+		const uint4 nextHeader = ld4(rec);
+		const uint4 nextQueue = ld4(rec + 1);
 
 		// ---- the current column, exactly as the reference processes it
 		if (COUNT) {
@@ -768,7 +788,10 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 // render kernel: grid = tiles, block = 64 (one wave).  LDS: words*64 uint32.
 // ---------------------------------------------------------------------------
 template <bool COUNT>
-__global__ __launch_bounds__(CVX_WAVE, 4) void render_kernel(const DevFrame *__restrict__ frames, const DevTile *__restrict__ tiles,
+#ifndef CVX_WAVES_PER_SIMD
+#define CVX_WAVES_PER_SIMD 4
+#endif
+__global__ __launch_bounds__(CVX_WAVE, CVX_WAVES_PER_SIMD) void render_kernel(const DevFrame *__restrict__ frames, const DevTile *__restrict__ tiles,
                                                           const DevWorld *__restrict__ world, DevCounters *__restrict__ counters)
 {
 	extern __shared__ uint32_t lds[];
@@ -790,7 +813,7 @@ __global__ __launch_bounds__(CVX_WAVE, 4) void render_kernel(const DevFrame *__r
 	const int firstLane = tile.lanes & 0xFF, laneCount = tile.lanes ? (tile.lanes >> 8) & 0xFF : CVX_WAVE;
 	const int planeRayIndex = tile.tileInSeg * CVX_WAVE + firstLane + lane;
 	const bool active = lane < laneCount && planeRayIndex < S.rayCount;
-	uint32_t *out = tile.out + firstLane + lane;
+	const gptr_out out = (gptr_out)tile.out + firstLane + lane;
 	uint32_t *seen = lds + lane - wordBase * CVX_WAVE;
 	ProfLane prof;
 #ifdef CVX_PROFILE_SECTIONS

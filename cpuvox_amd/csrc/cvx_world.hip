@@ -60,7 +60,10 @@ int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byt
 	if (!IsPow2(dimX) || !IsPow2(dimY) || !IsPow2(dimZ) || dimY > 65536) {
 		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "world dimensions must be powers of two (WordBuilder.cs:30), Y <= 65536");
 	}
-	if (lod > 0 && (ctx->hostWorld.dimX != dimX || ctx->hostWorld.dimY != dimY || ctx->hostWorld.dimZ != dimZ) && ctx->levelSet[0]) {
+	if (lod > 0 && !ctx->levelSet[0]) {
+		return Fail(ctx, CVX_ERR_NOT_READY, "upload LOD 0 first: the other levels are checked against its dimensions (World.cs:47)");
+	}
+	if (lod > 0 && (ctx->hostWorld.dimX != dimX || ctx->hostWorld.dimY != dimY || ctx->hostWorld.dimZ != dimZ)) {
 		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "all LODs share the LOD-0 dimensions (World.cs:47)");
 	}
 	const int64_t usedX = dimX >> lod, usedZ = dimZ >> lod;
@@ -156,6 +159,16 @@ int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byt
 	L.shift = lod;
 	L.mulX = dimZ >> lod;
 	if (lod == 0) {
+		if (ctx->hostWorld.dimX != dimX || ctx->hostWorld.dimY != dimY || ctx->hostWorld.dimZ != dimZ) {
+			// a LOD 0 of other dimensions starts a new world: the tables of the old LOD 1..5 are indexed with the old
+			// dimensions and must not survive (the draw reports CVX_ERR_NOT_READY until all levels are uploaded again)
+			for (int l = 1; l < CVX_LOD_LEVELS; l++) {
+				if (ctx->levelHeaders[l]) { (void)hipFree(ctx->levelHeaders[l]); ctx->levelHeaders[l] = nullptr; }
+				if (ctx->levelElements[l]) { (void)hipFree(ctx->levelElements[l]); ctx->levelElements[l] = nullptr; }
+				ctx->levelSet[l] = false;
+				ctx->hostWorld.level[l] = DevWorldLevel{};
+			}
+		}
 		ctx->hostWorld.dimX = dimX;
 		ctx->hostWorld.dimY = dimY;
 		ctx->hostWorld.dimZ = dimZ;
@@ -323,6 +336,12 @@ int cvx_world_downsample(cvx_context *ctx, const void *storage, int64_t byteLeng
 	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
 	if (!outStorage || !outByteLength || !outColumnCount) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "bad arguments"); }
 	*outStorage = nullptr;
+	if (lod != 0) {
+		// The reference only ever downsamples LOD 0 (UnityManager.cs:328-331: worldLODs[i] = worldLODs[0].DownSample(i)); for a source
+		// of lod > 0 its DownSamplePartial shifts source-LOD heights by lod + extraLods (World.cs:108-124), which squashes the column
+		// and is not a result worth reproducing -- refuse instead of returning a blob that differs from the host build.
+		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "cvx_world_downsample takes the LOD 0 blob (lod = %d given): World.DownSample is only defined for LOD 0 sources", lod);
+	}
 	uint8_t *dSrc = nullptr;
 	int rc = UploadSourceBlob(ctx, storage, byteLength, dimX, dimY, dimZ, lod, columnCount, &dSrc);
 	if (rc != CVX_OK) { return rc; }

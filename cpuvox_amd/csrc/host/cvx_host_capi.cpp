@@ -107,6 +107,8 @@ int cvxh_world_from_blobs(int dimX, int dimY, int dimZ, int count, const void *c
 		for (int i = 0; i < count; i++) {
 			const int64_t headerBytes = ((int64_t)dimX * dimZ) / ((int64_t)(i + 1) * (i + 1)) * 12; // World.ColumnCount, World.cs:17
 			if (!blobs[i] || byteLengths[i] < headerBytes) { return Fail("blob " + std::to_string(i) + " is shorter than its column table"); }
+			std::string why;
+			if (!cvx::World::ValidateBlob(dims, i, blobs[i], byteLengths[i], &why)) { return Fail(why); }
 			set->worlds.emplace_back(dims, i, blobs[i], byteLengths[i]);
 		}
 		*out = set.release();

@@ -156,6 +156,52 @@ World::World(int3 dimensions_, int lod_, const void *data, int64_t byteLength) :
 	elementAllocationCount = byteLength > headerBytes ? (byteLength - headerBytes) / 4 : 0;
 }
 
+bool World::ValidateBlob(int3 dims, int lod, const void *data, int64_t byteLength, std::string *error)
+{
+	auto fail = [&](const std::string &what) {
+		if (error) { *error = what; }
+		return false;
+	};
+	auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+	if (!data || lod < 0 || lod > 15 || !pow2(dims.x) || !pow2(dims.y) || !pow2(dims.z) || dims.y > 65536 ||
+	    (dims.x >> lod) < 1 || (dims.y >> lod) < 1 || (dims.z >> lod) < 1 || (int64_t)dims.x * dims.z > (int64_t)INT_MAX) {
+		return fail("world dimensions must be powers of two that the LOD divides (WordBuilder.cs:30)");
+	}
+	const int64_t columnCount = ((int64_t)dims.x * dims.z) / ((int64_t)(lod + 1) * (lod + 1)); // World.cs:17
+	const int64_t usedColumns = (int64_t)(dims.x >> lod) * (dims.z >> lod);
+	if (byteLength < columnCount * 12 || usedColumns > columnCount) {
+		return fail("LOD " + std::to_string(lod) + ": blob shorter than its column table");
+	}
+	const int64_t elementCount = (byteLength - columnCount * 12) / 4;
+	const RLEColumn *columns = static_cast<const RLEColumn *>(data);
+	const RLEElement *elements = reinterpret_cast<const RLEElement *>(static_cast<const uint8_t *>(data) + columnCount * 12);
+	const int maxY = dims.y >> lod;
+	for (int64_t i = 0; i < usedColumns; i++) {
+		const RLEColumn &c = columns[i];
+		if (c.runCount == 0) { continue; }
+		const int64_t off = c.storageOffset;
+		if (off < 0 || off + c.runCount + 2 > elementCount) {
+			return fail("LOD " + std::to_string(lod) + " column " + std::to_string(i) + ": element range outside the pool");
+		}
+		if (elements[off].Length != 0 || elements[off].ColorsIndex != 0 || elements[off + c.runCount + 1].Length != 0 || elements[off + c.runCount + 1].ColorsIndex != 0) {
+			return fail("LOD " + std::to_string(lod) + " column " + std::to_string(i) + ": missing element guards (World.cs:205-209)");
+		}
+		int64_t total = 0, colours = 0;
+		for (int r = 0; r < c.runCount; r++) {
+			const RLEElement e = elements[off + 1 + r];
+			if (e.Length <= 0) {
+				return fail("LOD " + std::to_string(lod) + " column " + std::to_string(i) + ": run with non-positive length");
+			}
+			total += e.Length;
+			if (e.ColorsIndex >= 0 && (int64_t)e.ColorsIndex + e.Length > colours) { colours = (int64_t)e.ColorsIndex + e.Length; }
+		}
+		if (total > maxY || off + c.runCount + 2 + colours > elementCount) {
+			return fail("LOD " + std::to_string(lod) + " column " + std::to_string(i) + ": runs exceed the world height or colours exceed the pool");
+		}
+	}
+	return true;
+}
+
 void World::StoreColumn(int index, const FinalColumn &column)
 {
 	RLEColumn *pointer = Columns() + index;
@@ -392,6 +438,10 @@ bool DeserializeWorlds(const std::string &filePath, std::vector<World> &worlds, 
 		return false;
 	}
 	SaveHeader header{};
+	std::string detail;
+	int64_t fileSize = 0;
+	if (std::fseek(f, 0, SEEK_END) == 0) { fileSize = (int64_t)std::ftell(f); }
+	std::rewind(f);
 	bool ok = std::fread(&header, sizeof header, 1, f) == 1 && header.WorldCount > 0 && header.WorldCount <= 64;
 	std::vector<int64_t> offsets;
 	if (ok) {
@@ -402,8 +452,15 @@ bool DeserializeWorlds(const std::string &filePath, std::vector<World> &worlds, 
 	for (int i = 0; ok && i < header.WorldCount; i++) {
 		int64_t offset = offsets[(size_t)i * 2];
 		int64_t count = offsets[(size_t)i * 2 + 1];
+		if (offset < 0 || count < 0 || count > fileSize || offset > fileSize - count) { // the table is untrusted input
+			ok = false;
+			break;
+		}
 		std::vector<uint8_t> blob((size_t)count);
 		ok = std::fseek(f, (long)offset, SEEK_SET) == 0 && std::fread(blob.data(), 1, blob.size(), f) == blob.size();
+		if (ok && !World::ValidateBlob(dims, i, blob.data(), count, &detail)) {
+			ok = false;
+		}
 		if (ok) {
 			worlds.emplace_back(dims, i, blob.data(), count);
 		}
@@ -411,7 +468,7 @@ bool DeserializeWorlds(const std::string &filePath, std::vector<World> &worlds, 
 	std::fclose(f);
 	if (!ok) {
 		worlds.clear();
-		if (error) { *error = "malformed world file " + filePath; }
+		if (error) { *error = "malformed world file " + filePath + (detail.empty() ? "" : ": " + detail); }
 	}
 	return ok;
 }

@@ -101,6 +101,11 @@ public:
 	// World.DownSample, World.cs:45-69
 	World DownSample(int extraLods, int64_t *voxelCount, int threads) const;
 
+	// Checks a blob that came from outside (a .world file, cvxh_world_from_blobs) before anything walks it: power-of-two
+	// dimensions, the column table inside the blob, and for every used column the element range, both guards
+	// (World.cs:205-209), positive run lengths that fit the column height and colours inside the pool.
+	static bool ValidateBlob(int3 dimensions, int lod, const void *data, int64_t byteLength, std::string *error);
+
 private:
 	void DownSamplePartial(int x, int z, int extraLods, RLEColumnBuilder &builder) const; // World.cs:101-127
 

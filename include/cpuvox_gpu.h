@@ -225,7 +225,8 @@ int cvx_debug_section_cycles(cvx_context *ctx, uint64_t out[32], int reset); /* 
 
 /* World.DownSample(extraLods) (Assets/Code/World.cs:45-127: DownSampleColumn :71-96, DownSamplePartial :101-127, with
  * RLEColumnBuilder.ToFinalColumn WordBuilder.cs:181-268 and the RLEColumn constructor World.cs:190-234) as a device
- * kernel: builds LOD lod+extraLods from the LOD `lod` blob (same layout as cvx_world_upload takes) and returns the new
+ * kernel: builds LOD extraLods from the LOD 0 blob (same layout as cvx_world_upload takes; `lod` must be 0 -- the reference only
+ * downsamples LOD 0, UnityManager.cs:328-331, other values are refused with CVX_ERR_INVALID_ARGUMENT) and returns the new
  * blob in the reference's storage layout, byte-identical to the host build (columns stored in index order), in memory
  * owned by the library: release it with cvx_free.  outColumnCount = World.ColumnCount of the new level (World.cs:17),
  * outVoxelCount (may be NULL) = voxels after deduplication, outDeviceMs (may be NULL) = device time of the two passes

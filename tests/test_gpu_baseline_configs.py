@@ -1,0 +1,192 @@
+"""-m gpu: BASELINE.json configs 3, 4 and 5 at their FULL sizes, HIP path (through the C ABI) against the CPU oracle.
+
+  config 3  procedural 2048^3 world, 1920x1080, lodError 1 (the bench workload): benchmark-path poses covering both
+            element iteration directions and LOD 0, 1 and 2 -- once as single cvx_draw_segments calls, once as ONE
+            64-frame cvx_draw_segments_batch launch (the shape bench.py times)
+  config 4  procedural 2048^3 world, 3840x2160, vanishing point on screen (12 000 rays)
+  config 5  procedural 4096^3 world (full height), 3840x2160, forward.y = +-0.001 (UnityManager.cs:193-201),
+            lodError 4 so that LOD 0..4 are visited (DrawSegmentRayJob.cs:237-243)
+
+Bar: bit-exact ARGB32 raybuffers, identical work counters (S, E, C, P, R and the per-LOD column visits).
+"""
+import numpy as np
+import pytest
+
+import oraclelib as O
+import scenes
+from cpuvox_amd import gpu, host
+
+pytestmark = pytest.mark.gpu
+
+CLEAR = 0xDEADBEEF
+POSES = 1000  # bench.py: pose index i -> clip time i / POSES * BENCHMARK_PATH_LENGTH
+# indices along the benchmark path: 0..450 look up (inverse iteration, one clamped segment), 500.. look down
+# (forward iteration); 550..950 have the vanishing point on or near the screen (up to 4 segments, 6000 rays)
+CONFIG3_POSES = [0, 50, 200, 300, 450, 500, 550, 650, 700, 800, 950]
+
+
+def _path_frame(ws, W, H, index, lods, far):
+    t = index / POSES * host.BENCHMARK_PATH_LENGTH
+    pos, eul = host.sample_benchmark_path(t, ws.dims)
+    return host.setup_frame(host.camera_pose(pos, eul, W, H), lods, far, W, H, ws.dims[1])
+
+
+def _lods(ws, W, H, lod_error):
+    return host.setup_lods(host.camera_pose((0, 0, 0), (0, 0, 0), W, H), ws.max_dimension, W, H, lod_error)
+
+
+def _compare(name, fr, g_td, g_lr, o_td, o_lr):
+    n_td, n_lr = scenes.used_rows(fr)
+    for label, g, o, n in (("topdown", g_td, o_td, n_td), ("leftright", g_lr, o_lr, n_lr)):
+        diff = g[:n] != o[:n]
+        if diff.any():
+            rows, cols = np.nonzero(diff)
+            raise AssertionError(f"{name}/{label}: {diff.sum()} of {diff.size} pixels differ; first at ray {rows[0]} pixel {cols[0]}: "
+                                 f"gpu {g[rows[0], cols[0]]:08x} oracle {o[rows[0], cols[0]]:08x}; rays affected {len(set(rows.tolist()))}")
+        assert (g[n:] == CLEAR).all(), f"{name}/{label}: rows beyond the used rays were written"
+
+
+def _same_counters(name, gc, oc):
+    assert (gc.S, gc.E, gc.C, gc.P, gc.R) == (oc.S, oc.E, oc.C, oc.P, oc.R), (name, gc.as_dict(), oc.as_dict())
+    assert list(gc.lodVisits) == list(oc.lodVisits), (name, list(gc.lodVisits), list(oc.lodVisits))
+
+
+@pytest.fixture(scope="module")
+def proc2048():
+    ws = scenes.load_world("proc2048")
+    ctx = gpu.Context(0, buffer_count=64)
+    ctx.upload_world(ws)
+    yield ws, ctx
+    ctx.close()
+
+
+def test_config3_single_draws(proc2048):
+    ws, ctx = proc2048
+    W, H = 1920, 1080
+    ctx.set_resolution(W, H)
+    lods, far = _lods(ws, W, H, 1.0)
+    assert lods[:3] == [1176.0, 2351.0, 8192.0] and far == 4096.0  # LOD 0-2 reachable
+    seen_lods = np.zeros(6, dtype=np.int64)
+    directions = set()
+    for index in CONFIG3_POSES:
+        fr = _path_frame(ws, W, H, index, lods, far)
+        directions.add(int(fr.camera.InverseElementIterationDirection))
+        ctx.enable_counters(True)
+        ctx.clear_raybuffers(0, CLEAR)
+        ctx.draw_segments(fr, 0)
+        gc = ctx.counters()
+        o_td, o_lr, oc = O.draw_segments(ws, fr, W, H, clear=CLEAR)
+        _compare(f"config3 pose {index}", fr, ctx.read_raybuffer(0, 0), ctx.read_raybuffer(0, 1), o_td, o_lr)
+        _same_counters(f"config3 pose {index}", gc, oc)
+        seen_lods += np.array(list(oc.lodVisits))
+    assert directions == {0, 1}, "both element iteration directions must occur"
+    assert (seen_lods[:3] > 0).all() and (seen_lods[3:] == 0).all(), seen_lods
+
+
+def test_config3_one_64_frame_batch(proc2048):
+    """The shape bench.py times: 64 frames in ONE launch (no sub-tile split at this size), every frame against the oracle."""
+    ws, ctx = proc2048
+    W, H = 1920, 1080
+    ctx.set_resolution(W, H)
+    lods, far = _lods(ws, W, H, 1.0)
+    indices = CONFIG3_POSES + [(g * 37) % POSES for g in range(64 - len(CONFIG3_POSES))]  # + the first bench poses (stride 37)
+    frames = [_path_frame(ws, W, H, i, lods, far) for i in indices]
+    for b in range(64):
+        ctx.clear_raybuffers(b, CLEAR)
+    ctx.enable_counters(True)
+    ctx.draw_segments_batch(frames, 0)
+    gc = ctx.counters()
+    total = O.OrcCounters()
+    for b, fr in enumerate(frames):
+        o_td, o_lr, oc = O.draw_segments(ws, fr, W, H, clear=CLEAR)
+        _compare(f"config3 batch frame {b} (pose {indices[b]})", fr, ctx.read_raybuffer(b, 0), ctx.read_raybuffer(b, 1), o_td, o_lr)
+        for k in ("S", "E", "C", "P", "R"):
+            setattr(total, k, getattr(total, k) + getattr(oc, k))
+        for l in range(6):
+            total.lodVisits[l] += oc.lodVisits[l]
+    _same_counters("config3 batch", gc, total)
+
+
+def test_config4_4k_vp_on_screen(proc2048):
+    ws, ctx = proc2048
+    W, H = 3840, 2160
+    ctx.set_resolution(W, H)
+    lods, far = _lods(ws, W, H, 1.0)
+    for index in (650, 800):
+        fr = _path_frame(ws, W, H, index, lods, far)
+        assert abs(fr.totalRays - 12000) <= 2 and all(s.RayCount > 0 for s in fr.segments)
+        ctx.enable_counters(True)
+        ctx.clear_raybuffers(0, CLEAR)
+        ctx.draw_segments(fr, 0)
+        gc = ctx.counters()
+        o_td, o_lr, oc = O.draw_segments(ws, fr, W, H, clear=CLEAR)
+        _compare(f"config4 pose {index}", fr, ctx.read_raybuffer(0, 0), ctx.read_raybuffer(0, 1), o_td, o_lr)
+        _same_counters(f"config4 pose {index}", gc, oc)
+
+
+def test_config5_4096_cubed_horizontal_deep_lods():
+    ws = scenes.load_world("proc4096")
+    assert tuple(ws.dims) == (4096, 4096, 4096)
+    W, H = 3840, 2160
+    ctx = gpu.Context(0)
+    try:
+        ctx.upload_world(ws)
+        ctx.set_resolution(W, H)
+        poses = [((-0.1, 0.5, -0.1), (0.0, 45.0, 0.0)),      # outside the world, forward.y clamped to +0.001: LOD 0..4
+                 ((0.4, 0.9, 0.3), (0.01, 200.0, 0.0)),      # inside, forward.y clamped to -0.001, forward iteration
+                 ((0.5, 0.6, 0.5), (0.0, 100.0, 0.0)),       # inside, +0.001
+                 ((0.3, 0.35, 0.7), (20.0, 310.0, 0.0))]     # VP on screen at 4K on the deep world (12 000 rays)
+        seen = np.zeros(6, dtype=np.int64)
+        for i, (frac, eul) in enumerate(poses):
+            pos = [frac[k] * ws.dims[k] for k in range(3)]
+            fr = scenes.make_frame(ws, W, H, pos, eul, lod_error=4.0)
+            if i < 3:
+                assert abs(abs(fr.forward[1]) - 0.001) < 1e-6
+            ctx.enable_counters(True)
+            ctx.clear_raybuffers(0, CLEAR)
+            ctx.draw_segments(fr, 0)
+            gc = ctx.counters()
+            o_td, o_lr, oc = O.draw_segments(ws, fr, W, H, clear=CLEAR)
+            _compare(f"config5 pose {i}", fr, ctx.read_raybuffer(0, 0), ctx.read_raybuffer(0, 1), o_td, o_lr)
+            _same_counters(f"config5 pose {i}", gc, oc)
+            seen += np.array(list(oc.lodVisits))
+        assert (seen[:5] > 0).all(), f"LOD 0..4 must be visited: {seen}"
+    finally:
+        ctx.close()
+
+
+def test_new_lod0_dimensions_invalidate_the_old_lod_chain():
+    """LOD 0 of other dimensions starts a new world; the old LOD 1..5 tables must not be indexed with it."""
+    small, big = scenes.load_world("proc256"), scenes.load_world("proc512")
+    ctx = gpu.Context(0)
+    try:
+        ctx.upload_world(small)
+        ctx.set_resolution(320, 200)
+        fr = scenes.benchmark_frame(big, 320, 200, 0.5)
+        i = big.info(0)
+        ctx._check(gpu.lib().cvx_world_upload(ctx._h, 0, i.storage, i.byteLength, i.dimX, i.dimY, i.dimZ, i.columnCount))
+        with pytest.raises(gpu.CvxError, match="LOD 1 has not been uploaded"):
+            ctx.draw_segments(fr, 0)
+        ctx.upload_world(big)  # the whole chain: fine again
+        ctx.clear_raybuffers(0, CLEAR)
+        ctx.draw_segments(fr, 0)
+        o_td, o_lr, _ = O.draw_segments(big, fr, 320, 200, clear=CLEAR, counters=False)
+        _compare("after re-upload", fr, ctx.read_raybuffer(0, 0), ctx.read_raybuffer(0, 1), o_td, o_lr)
+        fresh = gpu.Context(0)
+        j = small.info(1)
+        with pytest.raises(gpu.CvxError, match="LOD 0 first"):
+            fresh._check(gpu.lib().cvx_world_upload(fresh._h, 1, j.storage, j.byteLength, j.dimX, j.dimY, j.dimZ, j.columnCount))
+        fresh.close()
+    finally:
+        ctx.close()
+
+
+def test_downsample_refuses_a_non_lod0_source():
+    """World.DownSample is only ever applied to LOD 0 (UnityManager.cs:328-331); other sources are refused."""
+    ws = scenes.load_world("proc256")
+    ctx = gpu.Context(0)
+    try:
+        with pytest.raises(gpu.CvxError, match="LOD 0"):
+            ctx.downsample(ws, 1, 1)
+    finally:
+        ctx.close()
