@@ -49,6 +49,7 @@ def parse_args():
     ap.add_argument("--world", default="proc2048", help="proc<dim> | mill512 | mill256")
     ap.add_argument("--lod-error", type=float, default=1.0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="wall time of the cpu_baseline sample at N = 1 (0 = skip)")
+    ap.add_argument("--pose-range", default=None, help="diagnostics: lo:hi -- only benchmark-path samples lo <= i < hi (e.g. 0:450 = one top/bottom segment per frame)")
     ap.add_argument("--no-exchange", action="store_true", help="N > 1: skip the RCCL tile exchange (replica-style throughput)")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: finish each step's exchange before the next render")
     ap.add_argument("--pmc-csv", default=None, help="counter summary of a rocprofv3 --pmc run of THIS command (tools/pmc_passes.sh + "
@@ -122,7 +123,11 @@ def main():
     G = N * F  # frames per step, whole job
 
     def frame_for(g: int):
-        t = ((g * POSE_STRIDE) % POSES) / POSES * host.BENCHMARK_PATH_LENGTH
+        i = (g * POSE_STRIDE) % POSES
+        if args.pose_range:
+            lo, hi = (int(v) for v in args.pose_range.split(":"))
+            i = lo + i % (hi - lo)
+        t = i / POSES * host.BENCHMARK_PATH_LENGTH
         pos, eul = host.sample_benchmark_path(t, dims)
         return host.setup_frame(host.camera_pose(pos, eul, W, H), lods, far, W, H, dims[1])
 

@@ -79,13 +79,16 @@ struct cvx_context {
 	std::vector<DevTile> hostTiles;
 	std::vector<float> hostTileCost; // estimated DDA steps of the tile's middle ray (launch order: longest first)
 	std::vector<int> hostTileWords;  // LDS mask words per lane the tile needs
-	int maskWordsNeeded = 1;         // LDS mask words per lane the current launch needs (widest [origMin, origMax] window)
+	int maskWordsNeeded = 1;         // LDS mask words per lane of the widest [origMin, origMax] window in the current launch
+	int ldsWordsNeeded = CVX_WAVE;   // LDS words (mask words x lanes) of the largest wave of the current launch
+	int maxWaveMaskWords = 40 * CVX_WAVE; // LDS budget per wave: 10 KB = 16 waves per CU; wider tiles are cut into narrower waves
 
 	int shardIndex = 0, shardCount = 1;
 	bool countersEnabled = false;
 	DevCounters *devCounters = nullptr;
 	int splitWaveBudget = 4096;                // DrawBatch cuts tiles into sub-tiles while the launch stays below this many waves
 	int forcedSplit = 0;                       // CVX_TILE_SPLIT=1|2|...|64 (diagnostics): fixed split factor
+	int minMaskWords = 0;                      // CVX_MIN_MASK_WORDS (diagnostics): lower bound of the LDS mask words per lane, i.e. an occupancy cap
 };
 
 namespace cvxi {

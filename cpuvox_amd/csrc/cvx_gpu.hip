@@ -330,7 +330,7 @@ int Launch(cvx_context *ctx, int frameCount, int flags)
 		// runtime switch inside the kernel, so the tails of different frames overlap.  LDS = the widest seen-mask any
 		// tile of the batch needs.  (Splitting the batch into concurrent launches by LDS need was measured and lost:
 		// launches that share a hardware queue serialise, and more than ~10 resident waves per CU add nothing.)
-		const size_t ldsBytes = (size_t)ctx->maskWordsNeeded * CVX_WAVE * sizeof(uint32_t);
+		const size_t ldsBytes = (size_t)std::max(ctx->ldsWordsNeeded, ctx->minMaskWords * CVX_WAVE) * sizeof(uint32_t);
 		dim3 grid((unsigned)nTiles), block(CVX_WAVE);
 		if (ctx->countersEnabled) {
 			hipLaunchKernelGGL((cvxk::render_kernel<true>), grid, block, ldsBytes, ctx->stream, ctx->devFrames, ctx->devTiles, ctx->devWorld, ctx->devCounters);
@@ -384,6 +384,14 @@ int cvx_create(int device, cvx_context **out)
 		if (const char *v = std::getenv("CVX_TILE_SPLIT")) {
 			const int f = std::atoi(v);
 			if (f >= 1 && f <= CVX_WAVE && (f & (f - 1)) == 0) { ctx->forcedSplit = f; }
+		}
+		if (const char *v = std::getenv("CVX_MAX_WAVE_MASK_WORDS")) { // diagnostics: LDS budget per wave in mask words (x 4 bytes)
+			const int w = std::atoi(v);
+			if (w >= 64 && w <= 40960) { ctx->maxWaveMaskWords = w; }
+		}
+		if (const char *v = std::getenv("CVX_MIN_MASK_WORDS")) {
+			const int w = std::atoi(v);
+			if (w >= 1 && w <= 512) { ctx->minMaskWords = w; }
 		}
 	}
 	*out = ctx;
@@ -561,20 +569,31 @@ int DrawBatch(cvx_context *ctx, int frameCount, const cvx_segment_data *segments
 		int split = 1;
 		while (split < CVX_WAVE && n * (size_t)split * 2 <= (size_t)ctx->splitWaveBudget) { split *= 2; }
 		if (ctx->forcedSplit > 0) { split = ctx->forcedSplit; }
+		// LDS: the seen mask of a wave is words * lanes * 4 bytes.  Measured (profiles/r02_occupancy_sweep.txt): the kernel
+		// gains steadily up to the 16 waves per CU its 128 VGPRs allow, which needs <= 10 KB of LDS per wave = 40 words at 64
+		// lanes.  A tile whose window needs more words (a left / right segment spanning most of a 1920-pixel row, any
+		// segment at 4K) is therefore rendered by 2, 4, ... narrower waves, so ONE wide tile no longer takes the
+		// occupancy of the whole launch down.
 		std::vector<DevTile> sorted;
 		sorted.reserve(n * (size_t)split);
-		const int lanesPerWave = CVX_WAVE / split;
+		int ldsWords = 1; // words * lanes of the largest wave
 		for (size_t i = 0; i < n; i++) {
 			DevTile t = ctx->hostTiles[order[i]];
-			if (split == 1) {
+			const int words = ctx->hostTileWords[order[i]];
+			int tileSplit = split;
+			while (tileSplit < CVX_WAVE && words * (CVX_WAVE / tileSplit) > ctx->maxWaveMaskWords) { tileSplit *= 2; }
+			const int lanesPerWave = CVX_WAVE / tileSplit;
+			ldsWords = std::max(ldsWords, words * lanesPerWave);
+			if (tileSplit == 1) {
 				sorted.push_back(t);
 				continue;
 			}
-			for (int k = 0; k < split; k++) {
+			for (int k = 0; k < tileSplit; k++) {
 				t.lanes = (k * lanesPerWave) | (lanesPerWave << 8);
 				sorted.push_back(t);
 			}
 		}
+		ctx->ldsWordsNeeded = ldsWords;
 		ctx->hostTiles.swap(sorted);
 	}
 	return Launch(ctx, frameCount, flags);
@@ -818,6 +837,28 @@ int cvx_debug_section_cycles(cvx_context *ctx, uint64_t out[32], int reset)
 	(void)reset;
 	for (int i = 0; i < 32; i++) { out[i] = 0; }
 	return Fail(ctx, CVX_ERR_NOT_READY, "library was not built with -DCVX_PROFILE_SECTIONS (diagnostic build)");
+#endif
+}
+
+int cvx_debug_section_histogram(cvx_context *ctx, uint64_t out[128], int reset)
+{
+	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
+	if (!out) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "out is NULL"); }
+#if defined(CVX_PROFILE_SECTIONS) && defined(CVX_PROFILE_COUNTS)
+	CVX_HIP(ctx, hipSetDevice(ctx->device));
+	CVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	unsigned long long tmp[128];
+	CVX_HIP(ctx, hipMemcpyFromSymbol(tmp, HIP_SYMBOL(cvxk::g_sectionHist), sizeof tmp));
+	for (int i = 0; i < 128; i++) { out[i] = tmp[i]; }
+	if (reset) {
+		std::memset(tmp, 0, sizeof tmp);
+		CVX_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(cvxk::g_sectionHist), tmp, sizeof tmp));
+	}
+	return CVX_OK;
+#else
+	(void)reset;
+	for (int i = 0; i < 128; i++) { out[i] = 0; }
+	return Fail(ctx, CVX_ERR_NOT_READY, "library was not built with -DCVX_PROFILE_SECTIONS -DCVX_PROFILE_COUNTS (diagnostic build)");
 #endif
 }
 

@@ -205,19 +205,22 @@ __device__ __forceinline__ bool clip_world_bounds(f3 pMin, f3 pMax, float fMin, 
 }
 
 // ---- seen-pixel bitmask in LDS ---------------------------------------------
+// Word w of a lane lives at seen[w << sshift]: the words of the wave's lanes are interleaved with a stride of 64, or of
+// the lane count of a sub-tile (a tile whose window needs many words is rendered by narrower waves, so that every
+// launch stays within 10 KB of LDS per wave = 16 resident waves per CU, see DrawBatch).
 // first unseen pixel >= start, or omax+1; start unchanged when start > omax
 // (the reference's while loop at :407 / :678 does not run then).
-__device__ __forceinline__ int scan_up(const uint32_t *seen, int start, int omax)
+__device__ __forceinline__ int scan_up(const uint32_t *seen, int sshift, int start, int omax)
 {
 	if (start > omax) {
 		return start;
 	}
 	int w = start >> 5;
 	const int wend = omax >> 5;
-	uint32_t m = ~seen[w * CVX_WAVE] & (0xFFFFFFFFu << (start & 31));
+	uint32_t m = ~seen[w << sshift] & (0xFFFFFFFFu << (start & 31));
 	while (m == 0u && w < wend) {
 		w++;
-		m = ~seen[w * CVX_WAVE];
+		m = ~seen[w << sshift];
 	}
 	if (m == 0u) {
 		return omax + 1;
@@ -227,17 +230,17 @@ __device__ __forceinline__ int scan_up(const uint32_t *seen, int start, int omax
 }
 
 // last unseen pixel <= start, or omin-1; start unchanged when start < omin (:413 / :690).
-__device__ __forceinline__ int scan_down(const uint32_t *seen, int start, int omin)
+__device__ __forceinline__ int scan_down(const uint32_t *seen, int sshift, int start, int omin)
 {
 	if (start < omin) {
 		return start;
 	}
 	int w = start >> 5;
 	const int wbeg = omin >> 5;
-	uint32_t m = ~seen[w * CVX_WAVE] & (0xFFFFFFFFu >> (31 - (start & 31)));
+	uint32_t m = ~seen[w << sshift] & (0xFFFFFFFFu >> (31 - (start & 31)));
 	while (m == 0u && w > wbeg) {
 		w--;
-		m = ~seen[w * CVX_WAVE];
+		m = ~seen[w << sshift];
 	}
 	if (m == 0u) {
 		return omin - 1;
@@ -257,20 +260,20 @@ __device__ __forceinline__ uint32_t range_mask(int w, int lo, int hi)
 }
 
 // ReducePixelHorizon, DrawSegmentRayJob.cs:660-697
-__device__ __forceinline__ void reduce_pixel_horizon(const uint32_t *seen, int omin, int omax, int &rbMin, int &rbMax, int &nfMin, int &nfMax,
+__device__ __forceinline__ void reduce_pixel_horizon(const uint32_t *seen, int sshift, int omin, int omax, int &rbMin, int &rbMax, int &nfMin, int &nfMax,
                                                      float &frustumBoundsMin, float &frustumBoundsMax)
 {
 	if (rbMin <= nfMin) {
 		rbMin = nfMin;
 		if (rbMax >= nfMin) {
-			nfMin = scan_up(seen, rbMax + 1, omax);
+			nfMin = scan_up(seen, sshift, rbMax + 1, omax);
 			frustumBoundsMin = (float)nfMin - 0.501f;
 		}
 	}
 	if (rbMax >= nfMax) {
 		rbMax = nfMax;
 		if (rbMin <= nfMax) {
-			nfMax = scan_down(seen, rbMin - 1, omin);
+			nfMax = scan_down(seen, sshift, rbMin - 1, omin);
 			frustumBoundsMax = (float)nfMax + 0.501f;
 		}
 	}
@@ -294,7 +297,9 @@ struct ProfLane {
 #ifdef CVX_PROFILE_COUNTS
 // counting variant: [n] = number of times a wave executed the code at CVX_COUNT(n) (exactly one lane of the executing
 // wave increments), no time stamps
-#define CVX_COUNT(n) do { prof.lanes[n]++; if ((int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) { prof.acc[n]++; } } while (0)
+// plus a histogram of the number of active lanes per execution, 8 buckets of 8 lanes: g_sectionHist[n * 8 + (active - 1) / 8]
+__device__ unsigned long long g_sectionHist[CVX_NSEC * 8];
+#define CVX_COUNT(n) do { prof.lanes[n]++; const unsigned long long b_ = __ballot(1); if ((int)(threadIdx.x & 63) == __ffsll((long long)b_) - 1) { prof.acc[n]++; atomicAdd(&g_sectionHist[(n) * 8 + (__popcll(b_) - 1) / 8], 1ull); } } while (0)
 #define CVX_BEGIN() ((void)0)
 #define CVX_END(n) ((void)0)
 #else
@@ -321,7 +326,7 @@ struct LaneCounters {
 // ---------------------------------------------------------------------------
 template <int DIR, bool COUNT>
 __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S, const DevWorld *__restrict__ world, int planeRayIndex,
-                                          uint32_t *seen /* &lds[lane] */, gptr_out out /* tile + lane */, LaneCounters &cnt, ProfLane &prof)
+                                          uint32_t *seen /* &lds[lane] */, int sshift /* log2 of the mask word stride */, gptr_out out /* tile + lane */, LaneCounters &cnt, ProfLane &prof)
 {
 	(void)prof;
 	const int omin = S.omin, omax = S.omax;
@@ -465,10 +470,10 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 				return false;
 			}
 			if (writableMinPixel > nextFreePixelMin) {
-				nextFreePixelMin = scan_up(seen, writableMinPixel, omax);
+				nextFreePixelMin = scan_up(seen, sshift, writableMinPixel, omax);
 			}
 			if (writableMaxPixel < nextFreePixelMax) {
-				nextFreePixelMax = scan_down(seen, writableMaxPixel, omin);
+				nextFreePixelMax = scan_down(seen, sshift, writableMaxPixel, omin);
 			}
 			if (nextFreePixelMin > nextFreePixelMax) {
 				return false;
@@ -576,14 +581,14 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 					int rbMax = f2i(rintf(boundsY));
 					if (rbMax >= nextFreePixelMin && rbMin <= nextFreePixelMax) {
 						CVX_COUNT(10);
-						reduce_pixel_horizon(seen, omin, omax, rbMin, rbMax, nextFreePixelMin, nextFreePixelMax, frustumBoundsMin, frustumBoundsMax);
+						reduce_pixel_horizon(seen, sshift, omin, omax, rbMin, rbMax, nextFreePixelMin, nextFreePixelMax, frustumBoundsMin, frustumBoundsMax);
 						CVX_END(4);
 						for (int w = rbMin >> 5; w <= (rbMax >> 5); w++) { // pixel loop :519-533 over unseen bits
 							const uint32_t range = range_mask(w, rbMin, rbMax);
-							const uint32_t m = seen[w * CVX_WAVE];
+							const uint32_t m = seen[w << sshift];
 							uint32_t todo = ~m & range;
 							if (todo != 0u) {
-								seen[w * CVX_WAVE] = m | range;
+								seen[w << sshift] = m | range;
 								frustumDirMaxWorld = CVX_FLOAT_EPSILON;
 								do {
 									CVX_COUNT(5);
@@ -655,14 +660,14 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 				}
 				if (rbMax >= nextFreePixelMin && rbMin <= nextFreePixelMax) {
 					CVX_COUNT(12);
-					reduce_pixel_horizon(seen, omin, omax, rbMin, rbMax, nextFreePixelMin, nextFreePixelMax, frustumBoundsMin, frustumBoundsMax);
+					reduce_pixel_horizon(seen, sshift, omin, omax, rbMin, rbMax, nextFreePixelMin, nextFreePixelMax, frustumBoundsMin, frustumBoundsMax);
 					CVX_END(6);
 					for (int w = rbMin >> 5; w <= (rbMax >> 5); w++) { // :595-603
 						const uint32_t range = range_mask(w, rbMin, rbMax);
-						const uint32_t m = seen[w * CVX_WAVE];
+						const uint32_t m = seen[w << sshift];
 						uint32_t todo = ~m & range;
 						if (todo != 0u) {
-							seen[w * CVX_WAVE] = m | range;
+							seen[w << sshift] = m | range;
 							frustumDirMaxWorld = CVX_FLOAT_EPSILON;
 							do {
 								CVX_COUNT(7);
@@ -805,16 +810,18 @@ __global__ __launch_bounds__(CVX_WAVE, CVX_WAVES_PER_SIMD) void render_kernel(co
 	const int omin = S.omin, omax = S.omax;
 	const int wordBase = omin >> 5;
 	const int words = (omax >> 5) - wordBase + 1;
-	for (int w = 0; w < words; w++) {
-		lds[w * CVX_WAVE + lane] = 0u; // stackalloc is zero-initialised, :208
-	}
-
 	// RaySetupJob (:19-39): tile -> (segment, planeRayIndex)
 	const int firstLane = tile.lanes & 0xFF, laneCount = tile.lanes ? (tile.lanes >> 8) & 0xFF : CVX_WAVE;
+	const int sshift = 31 - __clz(laneCount); // laneCount is a power of two
 	const int planeRayIndex = tile.tileInSeg * CVX_WAVE + firstLane + lane;
 	const bool active = lane < laneCount && planeRayIndex < S.rayCount;
+	if (lane < laneCount) {
+		for (int w = 0; w < words; w++) {
+			lds[(w << sshift) + lane] = 0u; // stackalloc is zero-initialised, :208
+		}
+	}
 	const gptr_out out = (gptr_out)tile.out + firstLane + lane;
-	uint32_t *seen = lds + lane - wordBase * CVX_WAVE;
+	uint32_t *seen = lds + lane - (wordBase << sshift);
 	ProfLane prof;
 #ifdef CVX_PROFILE_SECTIONS
 	for (int i = 0; i < CVX_NSEC; i++) { prof.acc[i] = 0u; }
@@ -833,9 +840,9 @@ __global__ __launch_bounds__(CVX_WAVE, CVX_WAVES_PER_SIMD) void render_kernel(co
 	if (active) {
 		// RenderJob.Execute :174-178: the iteration direction is a per-frame (wave-uniform) constant
 		if (F.inverse) {
-			trace_ray<-1, COUNT>(F, S, world, planeRayIndex, seen, out, cnt, prof);
+			trace_ray<-1, COUNT>(F, S, world, planeRayIndex, seen, sshift, out, cnt, prof);
 		} else {
-			trace_ray<1, COUNT>(F, S, world, planeRayIndex, seen, out, cnt, prof);
+			trace_ray<1, COUNT>(F, S, world, planeRayIndex, seen, sshift, out, cnt, prof);
 		}
 	}
 
@@ -844,8 +851,8 @@ __global__ __launch_bounds__(CVX_WAVE, CVX_WAVES_PER_SIMD) void render_kernel(co
 	CVX_BEGIN();
 	unsigned int skyPixels = 0;
 	for (int w = omin >> 5; w <= (omax >> 5); w++) {
-		uint32_t todo = ~seen[w * CVX_WAVE] & range_mask(w, omin, omax);
-		if (!active) { todo = 0u; }
+		uint32_t todo = 0u;
+		if (active) { todo = ~seen[w << sshift] & range_mask(w, omin, omax); }
 		const int base = w << 5;
 #pragma unroll 4
 		for (int b = 0; b < 32; b++) {

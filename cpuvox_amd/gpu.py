@@ -29,7 +29,7 @@ EXPORTS = [
     "cvx_clear_raybuffer", "cvx_read_raybuffer", "cvx_blit_segments", "cvx_raybuffer_device_ptr",
     "cvx_screen_device_ptr", "cvx_last_draw_ms", "cvx_enable_counters", "cvx_get_counters",
     "cvx_get_raybuffer_layout", "cvx_selftest_math", "cvx_version", "cvx_bind_raybuffers", "cvx_draw_time_stats", "cvx_debug_section_cycles", "cvx_debug_occupancy", "cvx_copy_rows", "cvx_draw_segments_placed",
-    "cvx_world_downsample", "cvx_world_build_lods", "cvx_free",
+    "cvx_world_downsample", "cvx_world_build_lods", "cvx_free", "cvx_debug_section_histogram",
 ]
 
 
@@ -314,6 +314,13 @@ class Context:
         out = (C.c_uint64 * 32)()
         self._check(lib().cvx_debug_section_cycles(self._h, out, int(reset)))
         return list(out)
+
+    def debug_section_histogram(self, reset: bool = False):
+        """Counting diagnostic build only: [section][bucket of 8 lanes] executions (include/cpuvox_gpu.h)."""
+        out = (C.c_uint64 * 128)()
+        lib().cvx_debug_section_histogram.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
+        self._check(lib().cvx_debug_section_histogram(self._h, out, int(reset)))
+        return [list(out[i * 8:(i + 1) * 8]) for i in range(16)]
 
     def selftest_math(self, op: int, a: np.ndarray, b: np.ndarray) -> np.ndarray:
         a = np.ascontiguousarray(a, dtype=np.float32)

@@ -222,6 +222,9 @@ int cvx_debug_occupancy(cvx_context *ctx, int64_t ldsBytes, int *blocksPerCU);
  * (DDA step + header + cull), 2 frustum clip, 3 element walk, 4 side-face setup, 5 side-face pixels,
  * 6 top/bottom setup, 7 top/bottom pixels, 8 skybox pass.  The regular build returns CVX_ERR_NOT_READY. */
 int cvx_debug_section_cycles(cvx_context *ctx, uint64_t out[32], int reset); /* [16+i] = cycles/16 * active lanes of section i */
+/* Counting diagnostic build only (make gpu-count): how many lanes were active each time a wave executed section i:
+ * out[i * 8 + b] = executions with 8b+1 .. 8b+8 active lanes. */
+int cvx_debug_section_histogram(cvx_context *ctx, uint64_t out[128], int reset);
 
 /* World.DownSample(extraLods) (Assets/Code/World.cs:45-127: DownSampleColumn :71-96, DownSamplePartial :101-127, with
  * RLEColumnBuilder.ToFinalColumn WordBuilder.cs:181-268 and the RLEColumn constructor World.cs:190-234) as a device

@@ -23,6 +23,7 @@ ctx = gpu.Context(0, buffer_count=frames_n)
 ctx.upload_world(ws)
 ctx.set_resolution(W, H)
 ctx.debug_section_cycles(reset=True)
+ctx.debug_section_histogram(reset=True)
 ctx.enable_counters(True)
 ctx.draw_segments_batch(frames, 0)
 c = ctx.counters()
@@ -30,3 +31,8 @@ cyc = ctx.debug_section_cycles()
 print(f"{frames_n} frames: lane-level S={c.S} E={c.E} C={c.C} P={c.P} R={c.R}")
 for k in (1, 8, 2, 3, 4, 9, 10, 5, 6, 11, 12, 7):
     print(f"{NAMES[k]:40s} {cyc[k]:12d}  per wave-step {cyc[k] / max(1, cyc[1]):6.3f}   active lanes per execution {cyc[16 + k] / max(1, cyc[k]):5.1f}")
+hist = ctx.debug_section_histogram()
+print("active lanes per execution, share of executions in buckets 1-8, 9-16, ..., 57-64:")
+for k in (1, 8, 2, 3, 4, 10, 5, 6, 12, 7):
+    tot = max(1, sum(hist[k]))
+    print(f"{NAMES[k]:40s} " + " ".join(f"{100.0 * v / tot:5.1f}" for v in hist[k]))
