@@ -59,6 +59,64 @@ __device__ __forceinline__ int f2i(float x)
 	return (x < 2147483648.0f) ? r : (int)0x80000000;
 }
 
+// (int)floorf(x) with the same rule: v_cvt_flr_i32_f32 floors and converts in one instruction (saturating, NaN -> 0)
+__device__ __forceinline__ int f2i_floor(float x)
+{
+	int r;
+	asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+	return (x < 2147483648.0f) ? r : (int)0x80000000;
+}
+
+// Unity.Mathematics min / max as ONE instruction, for call sites where no operand can be a negative zero (or where the sign of
+// a zero result cannot be observed): v_min_f32 / v_max_f32 return the other operand when one is a NaN, exactly like m_min /
+// m_max above, and differ from them only in min(-0, +0) = -0 (m_min: +0), max(+0, -0) = +0 (m_max: -0) and for a SIGNALLING NaN
+// operand (returned quieted; arithmetic only ever produces quiet NaNs and non-finite inputs are rejected by the library).  m_min costs two
+// compares and a select, all three half-rate instructions on gfx950 (tools/valu_rate.hip).
+__device__ __forceinline__ float hw_min(float x, float y)
+{
+	float r;
+	asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+	return r;
+}
+__device__ __forceinline__ float hw_max(float x, float y)
+{
+	float r;
+	asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+	return r;
+}
+
+// ---- exact f32 division without the scaling steps ---------------------------------------------------------------------
+// The compiler expands a / b into v_div_scale (b), v_rcp, fma, fma [refined reciprocal r], v_div_scale (a), mul, fma, fma, fma
+// [q = a * r, two residual corrections and a last residual], v_div_fmas, v_div_fixup.  When the magnitudes of a and b lie
+// in [2^-30, 2^30], none of v_div_scale's cases applies (exponent difference < 96, nothing denormal, numerator not tiny): both
+// return their operand unchanged with VCC = 0, v_div_fmas is then a plain fma and v_div_fixup passes its input through (finite
+// non-zero operands, quotient in [2^-60, 2^60]).  What is left is rcp + 2 fma per DENOMINATOR and mul + 4 fma per NUMERATOR:
+// the same operations on the same values in the same order, hence the same bits as `a / b` -- by construction, and checked
+// against IEEE division by cvx_selftest_math ops 10 / 11.  A block that divides several numerators by one denominator pays
+// the reciprocal once; operands outside the range (zero, denormal, huge, infinite, NaN) take the ordinary division.
+struct Recip {
+	float r, negd;
+};
+__device__ __forceinline__ bool div_safe(float x)
+{
+	return __builtin_amdgcn_fmed3f(fabsf(x), 0x1p-30f, 0x1p30f) == fabsf(x); // false for 0, denormals, NaN, infinities
+}
+__device__ __forceinline__ Recip recip_safe(float d)
+{
+	float r = __builtin_amdgcn_rcpf(d);
+	const float e = __builtin_fmaf(-d, r, 1.0f);
+	r = __builtin_fmaf(e, r, r);
+	return { r, -d };
+}
+__device__ __forceinline__ float quot_safe(float n, Recip R)
+{
+	float q = n * R.r;
+	float e = __builtin_fmaf(R.negd, q, n);
+	q = __builtin_fmaf(e, R.r, q);
+	e = __builtin_fmaf(R.negd, q, n);
+	return __builtin_fmaf(e, R.r, q);
+}
+
 struct f3 {
 	float x, y, z;
 };
@@ -91,14 +149,16 @@ __device__ __forceinline__ void dda_init(DDA &d, float startX, float startZ, flo
 	d.distNext = m_min(d.tMaxX, d.tMaxZ);
 }
 
-__device__ __forceinline__ void dda_next_lod(DDA &d, int currentVoxelSize) // :31-73
+// dirXNonNegative / dirZNonNegative = (dir.x >= 0), (dir.y >= 0): per-ray constants the caller evaluates once (they live in scalar
+// lane masks, so the direction itself need not stay in vector registers for the whole column loop)
+__device__ __forceinline__ void dda_next_lod(DDA &d, int currentVoxelSize, bool dirXNonNegative, bool dirZNonNegative) // :31-73
 {
 	int remX = d.px & (currentVoxelSize * 2 - 1);
 	int remZ = d.pz & (currentVoxelSize * 2 - 1);
 	float prevX = d.tMaxX - d.tDeltaX;
 	float prevZ = d.tMaxZ - d.tDeltaZ;
-	if ((d.dirX >= 0.0f) == (remX < currentVoxelSize)) { d.tMaxX += d.tDeltaX; } else { prevX -= d.tDeltaX; }
-	if ((d.dirZ >= 0.0f) == (remZ < currentVoxelSize)) { d.tMaxZ += d.tDeltaZ; } else { prevZ -= d.tDeltaZ; }
+	if (dirXNonNegative == (remX < currentVoxelSize)) { d.tMaxX += d.tDeltaX; } else { prevX -= d.tDeltaX; }
+	if (dirZNonNegative == (remZ < currentVoxelSize)) { d.tMaxZ += d.tDeltaZ; } else { prevZ -= d.tDeltaZ; }
 	d.distLast = m_max(prevX, prevZ);
 	d.distNext = m_min(d.tMaxX, d.tMaxZ);
 	d.px -= remX;
@@ -164,7 +224,7 @@ __device__ __forceinline__ bool dda_step(DDA &d, float farClip) // :135-150
 	d.px += stepX ? d.sx : 0;
 	d.pz += stepX ? 0 : d.sz;
 	d.distLast = crossed;
-	d.distNext = m_min(d.tMaxX, d.tMaxZ);
+	d.distNext = hw_min(d.tMaxX, d.tMaxZ); // tMax values are sums of positive terms: no negative zero, m_min == v_min_f32
 	return crossed >= farClip;
 }
 
@@ -343,6 +403,8 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		dda_init(ray, F.posX, F.posZ, r * dx, r * dz);
 	}
 
+	const bool dirXNonNegative = ray.dirX >= 0.0f, dirZNonNegative = ray.dirZ >= 0.0f; // SegmentDDAData.cs:41,57
+
 	// ---- TraceToFirstColumnJob.Execute, :95-143
 	int lod = 0;
 	float lodMax = F.lod[0];
@@ -352,7 +414,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			return; // WriteSkyboxFull
 		}
 		while (ray.distLast >= lodMax && lod < 5) { // lod < 5: memory-safety guard only, such a ray is beyond far clip anyway
-			dda_next_lod(ray, 1 << lod);
+			dda_next_lod(ray, 1 << lod, dirXNonNegative, dirZNonNegative);
 			lod++;
 			lodMax = F.lod[lod];
 		}
@@ -408,6 +470,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 	int curScale;                     // voxelScale of the current column
 	gptr_u32 curElements;             // element pool of the current column's LOD (colours)
 	gptr_u2 curRuns;                  // overflow list (solid runs 2..) of the current column's LOD and walk direction
+	uint4 ext = { 0u, 0u, 0u, 0u };   // solid runs 2 and 3 of the current column (columns with more than two)
 	unsigned int consumed = 0u;       // counting variant: elements the reference's walk has dereferenced in this column
 	float worldBoundsMin, worldBoundsMax;
 
@@ -418,10 +481,6 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		CVX_BEGIN();
 		if (COUNT) { consumed = 0u; }
 		const gptr_u2 overflowRuns = curRuns + header.w - 2; // solid run k >= 2 lives at overflowRuns[k]
-		uint4 ext = { 0u, 0u, 0u, 0u };
-		if (solidCount > 2) {
-			ext = ld4((gptr_u4)(overflowRuns + 2)); // runs 2 and 3; issued now, the latency hides behind the clip / first run
-		}
 		// :289-293
 		const f3 camSpaceMinLast = f3_madd(planeStartBottom, planeDir, curDistLast);
 		const f3 camSpaceMinNext = f3_madd(planeStartBottom, planeDir, curDistNext);
@@ -432,7 +491,8 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		if (curDistLast > 2.0f && frustumDirMaxWorld == CVX_FLOAT_EPSILON) { // :295-422
 			CVX_COUNT(2);
 			float clipLastMinLerp, clipLastMaxLerp, clipNextMinLerp, clipNextMaxLerp;
-			const float invFrustumMin = 1.0f / frustumBoundsMin, invFrustumMax = 1.0f / frustumBoundsMax; // CameraData.cs:103,111
+			// CameraData.cs:103,111.  frustumBounds = (integer pixel in [-1, 16385]) -/+ 0.501: magnitude in [0.499, 16386], always "safe"
+			const float invFrustumMin = quot_safe(1.0f, recip_safe(frustumBoundsMin)), invFrustumMax = quot_safe(1.0f, recip_safe(frustumBoundsMax));
 			const bool clippedLast = clip_world_bounds(camSpaceMinLast, camSpaceMaxLast, frustumBoundsMin, frustumBoundsMax, invFrustumMin, invFrustumMax, clipLastMinLerp, clipLastMaxLerp);
 			const bool clippedNext = clip_world_bounds(camSpaceMinNext, camSpaceMaxNext, frustumBoundsMin, frustumBoundsMax, invFrustumMin, invFrustumMax, clipNextMinLerp, clipNextMaxLerp);
 
@@ -457,13 +517,14 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			float maxLast = maxClipA.x / maxClipA.z;
 			if (maxNext < minNext) { float t = maxNext; maxNext = minNext; minNext = t; }
 			if (maxLast < minLast) { float t = maxLast; maxLast = minLast; minLast = t; }
-			const float camSpaceClippedMin = clippedLast ? minNext : (clippedNext ? minLast : m_min(minLast, minNext));
-			const float camSpaceClippedMax = clippedLast ? maxNext : (clippedNext ? maxLast : m_max(maxLast, maxNext));
+			// (hw_min / hw_max: the results only go through floor / ceil and (int), which map -0 and +0 to the same 0)
+			const float camSpaceClippedMin = clippedLast ? minNext : (clippedNext ? minLast : hw_min(minLast, minNext));
+			const float camSpaceClippedMax = clippedLast ? maxNext : (clippedNext ? maxLast : hw_max(maxLast, maxNext));
 
 			worldBoundsMin = floorf(worldBoundsMin);
 			worldBoundsMax = ceilf(worldBoundsMax);
 
-			const int writableMinPixel = f2i(floorf(camSpaceClippedMin));
+			const int writableMinPixel = f2i_floor(camSpaceClippedMin);
 			const int writableMaxPixel = f2i(ceilf(camSpaceClippedMax));
 
 			if (writableMaxPixel < nextFreePixelMin || writableMinPixel > nextFreePixelMax) {
@@ -547,12 +608,28 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			f3 camSpaceFrontBottom = f3_lerp(camSpaceMinLast, camSpaceMaxLast, portionBottom);
 			f3 camSpaceFrontTop = f3_lerp(camSpaceMinLast, camSpaceMaxLast, portionTop);
 
+			// Which face follows the side (:549-565), decided here so that its colour (the run's first colour for a top face, its
+			// last for a bottom face, :553,560) is in flight while the side is projected and drawn.  The reference reads it after
+			// the side; a load has no side effect, and the counting build counts it where the reference reads it.
+			const bool faceTop = portionTop < cameraPosYNormalized;
+			const bool faceBottom = !faceTop && portionBottom > cameraPosYNormalized;
+			const bool faceWanted = faceTop ? !(elementBoundsMax > worldBoundsMax) : (faceBottom && !(elementBoundsMin < worldBoundsMin));
+			uint32_t secondaryColor = 0u;
+			if (faceWanted) {
+				secondaryColor = worldColumnColors[faceTop ? elementColorsIndex : elementColorsIndex + elementLength - 1];
+			}
+
 			// side of the run, :484-542
 			CVX_COUNT(4);
+			// x / z of the front end the face shares with the side (:570-571 project the same point again): kept from the side
+			// block unless the face's own near clip moves the point
+			float frontBottomQuotient, frontTopQuotient, sharedQuotient = 0.0f;
+			bool haveFrontQuotients;
 			{
 				float uA = (float)elementLength;
 				float uB = 0.0f;
 				bool visible = true; // ClipHomogeneousCameraSpaceLine with u, CameraData.cs:141-157
+				bool nearClipped = false;
 				if (camSpaceFrontBottom.y <= 0.0f) {
 					if (camSpaceFrontTop.y <= 0.0f) {
 						visible = false;
@@ -560,18 +637,40 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 						float v = camSpaceFrontTop.y / (camSpaceFrontTop.y - camSpaceFrontBottom.y);
 						camSpaceFrontBottom = f3_lerp(camSpaceFrontTop, camSpaceFrontBottom, v);
 						uA = m_lerp(uB, uA, v);
+						nearClipped = true;
 					}
 				} else if (camSpaceFrontTop.y <= 0.0f) {
 					float v = camSpaceFrontBottom.y / (camSpaceFrontBottom.y - camSpaceFrontTop.y);
 					camSpaceFrontTop = f3_lerp(camSpaceFrontBottom, camSpaceFrontTop, v);
 					uB = m_lerp(uA, uB, v);
+					nearClipped = true;
 				}
+				haveFrontQuotients = visible;
 				if (visible) {
 					CVX_COUNT(9);
-					float uvAx = 1.0f / camSpaceFrontBottom.z, uvAy = uA / camSpaceFrontBottom.z;
-					float uvBx = 1.0f / camSpaceFrontTop.z, uvBy = uB / camSpaceFrontTop.z;
-					float boundsX = camSpaceFrontBottom.x / camSpaceFrontBottom.z; // ProjectClippedToScreen, CameraData.cs:160
-					float boundsY = camSpaceFrontTop.x / camSpaceFrontTop.z;
+					// uvA = (1, uA) / bottom.z, uvB = (1, uB) / top.z (:490-493) and ProjectClippedToScreen (CameraData.cs:160) of both ends:
+					// three numerators per denominator.  Ordinary case (nothing near-clipped, so uA = the run length in [1, 65535] and
+					// uB = 0, and all of x, z of both ends within [2^-30, 2^30]): one refined reciprocal per end (see quot_safe).
+					float uvAx, uvAy, uvBx, uvBy;
+					if (!nearClipped && div_safe(camSpaceFrontBottom.z) && div_safe(camSpaceFrontTop.z) && div_safe(camSpaceFrontBottom.x) && div_safe(camSpaceFrontTop.x)) {
+						const Recip rb = recip_safe(camSpaceFrontBottom.z), rt = recip_safe(camSpaceFrontTop.z);
+						uvAx = quot_safe(1.0f, rb);
+						uvAy = quot_safe(uA, rb);
+						frontBottomQuotient = quot_safe(camSpaceFrontBottom.x, rb);
+						uvBx = quot_safe(1.0f, rt);
+						uvBy = __int_as_float(__float_as_int(camSpaceFrontTop.z) & (int)0x80000000); // +0 / z: a zero with the sign of z
+						frontTopQuotient = quot_safe(camSpaceFrontTop.x, rt);
+					} else {
+						uvAx = 1.0f / camSpaceFrontBottom.z;
+						uvAy = uA / camSpaceFrontBottom.z;
+						uvBx = 1.0f / camSpaceFrontTop.z;
+						uvBy = uB / camSpaceFrontTop.z;
+						frontBottomQuotient = camSpaceFrontBottom.x / camSpaceFrontBottom.z;
+						frontTopQuotient = camSpaceFrontTop.x / camSpaceFrontTop.z;
+					}
+					sharedQuotient = faceTop ? frontTopQuotient : frontBottomQuotient;
+					float boundsX = frontBottomQuotient;
+					float boundsY = frontTopQuotient;
 					if (boundsX > boundsY) {
 						float t = boundsX; boundsX = boundsY; boundsY = t;
 						t = uvAx; uvAx = uvBx; uvBx = t;
@@ -598,7 +697,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 									float wux = m_lerp(uvAx, uvBx, l);
 									float wuy = m_lerp(uvAy, uvBy, l);
 									float u = wuy / wux;
-									int colorIdx = m_clampi(f2i(floorf(u)), 0, elementLength - 1) + elementColorsIndex;
+									int colorIdx = m_clampi(f2i_floor(u), 0, elementLength - 1) + elementColorsIndex;
 									out[y * CVX_WAVE] = worldColumnColors[colorIdx];
 									if (COUNT) { cnt.C++; cnt.P++; }
 								} while (todo != 0u);
@@ -614,30 +713,17 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 
 			// top / bottom of the run, :544-610
 			CVX_END(4); // (remainder of) the side block
-			f3 secA, secB;
-			uint32_t secondaryColor;
-			if (portionTop < cameraPosYNormalized) {
-				if (elementBoundsMax > worldBoundsMax) {
-					continue;
-				}
-				secondaryColor = worldColumnColors[elementColorsIndex];
-				if (COUNT) { cnt.C++; }
-				secA = f3_lerp(camSpaceMinNext, camSpaceMaxNext, portionTop);
-				secB = camSpaceFrontTop;
-			} else if (portionBottom > cameraPosYNormalized) {
-				if (elementBoundsMin < worldBoundsMin) {
-					continue;
-				}
-				secondaryColor = worldColumnColors[elementColorsIndex + elementLength - 1];
-				if (COUNT) { cnt.C++; }
-				secA = f3_lerp(camSpaceMinNext, camSpaceMaxNext, portionBottom);
-				secB = camSpaceFrontBottom;
-			} else {
-				continue;
+			if (!faceWanted) {
+				continue; // seen from the side, or the face lies outside the world bounds (:551,558,564)
 			}
+			if (COUNT) { cnt.C++; }
+			f3 secA = f3_lerp(camSpaceMinNext, camSpaceMaxNext, faceTop ? portionTop : portionBottom);
+			f3 secB = faceTop ? camSpaceFrontTop : camSpaceFrontBottom;
+			float secBQuotient = sharedQuotient;
 
 			CVX_COUNT(6);
 			bool visible = true; // ClipHomogeneousCameraSpaceLine, CameraData.cs:124-138
+			bool secBKept = haveFrontQuotients; // secB is still the front end the side block projected
 			if (secA.y <= 0.0f) {
 				if (secB.y <= 0.0f) {
 					visible = false;
@@ -648,11 +734,15 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			} else if (secB.y <= 0.0f) {
 				float v = secA.y / (secA.y - secB.y);
 				secB = f3_lerp(secA, secB, v);
+				secBKept = false;
 			}
 			if (visible) {
 				CVX_COUNT(11);
 				float bx = rintf(secA.x / secA.z);
-				float by = rintf(secB.x / secB.z);
+				if (!secBKept) {
+					secBQuotient = secB.x / secB.z; // (a side that was entirely behind the near plane, or a clipped secB: rare)
+				}
+				float by = rintf(secBQuotient);
 				int rbMin = f2i(bx);
 				int rbMax = f2i(by);
 				if (rbMin > rbMax) {
@@ -693,7 +783,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 
 	// column 0: LOD check (:237-243), bounds test and fetch (World.GetVoxelColumn, World.cs:130-142)
 	if (ray.distLast >= lodMax && lod < 5) {
-		dda_next_lod(ray, voxelScale);
+		dda_next_lod(ray, voxelScale, dirXNonNegative, dirZNonNegative);
 		lod++;
 		voxelScale *= 2;
 		L = world->level[lod];
@@ -724,11 +814,16 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		curElements = (gptr_u32)L.elements;
 		curRuns = (gptr_u2)(DIR > 0 ? L.runsDown : L.runsUp);
 		const int curLod = lod;
+		// Runs 2 and 3 of the current column (3 % of the columns have them) are requested BEFORE the look-ahead record: vector
+		// memory returns in order, so the element walk can wait for them (vmcnt(2)) and leave the look-ahead in flight.
+		if ((header.y & 0xFFFFu) > 2u) {
+			ext = ld4((gptr_u4)(curRuns + header.w));
+		}
 		const bool lastColumn = dda_step(ray, farClip); // true: far clip reached after this column
 		// (the LOD check and the fetch are done for every lane, also one that stops after this column: its state is
 		// dead, and an unconditional, in-bounds load is cheaper than branching around it)
 		if (ray.distLast >= lodMax && lod < 5) {
-			dda_next_lod(ray, voxelScale);
+			dda_next_lod(ray, voxelScale, dirXNonNegative, dirZNonNegative);
 			lod++;
 			voxelScale *= 2;
 			L = world->level[lod];
@@ -1028,6 +1123,12 @@ __global__ void selftest_math_kernel(int op, int n, const float *__restrict__ a,
 	case 7: r = __int_as_float(f2i(x)); break;
 	case 8: r = x * y; break;
 	case 9: r = x + y; break;
+	case 10: r = (div_safe(x) && div_safe(y)) ? quot_safe(x, recip_safe(y)) : x / y; break; // the short division form, guarded as in the kernel
+	case 11: r = div_safe(y) ? quot_safe(1.0f, recip_safe(y)) : 1.0f / y; break;
+	case 12: r = __int_as_float(f2i_floor(x)); break;
+	case 13: r = hw_min(x, y); break;
+	case 14: r = hw_max(x, y); break;
+	case 15: r = div_safe(x) ? 1.0f : 0.0f; break;
 	default: r = 0.0f; break;
 	}
 	out[i] = r;

@@ -280,6 +280,65 @@ def test_device_float_contract(contexts):
         assert np.array_equal(ctx.selftest_math(7, a, b).view(np.int32), want)
 
 
+def _float_soup(rng, n):
+    """Random binary32 values over the whole exponent range, plus every special the kernel's guards have to route."""
+    bits = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32)
+    x = bits.view(np.float32).copy()
+    # a third of the values in the range the renderer actually produces (pixels, depths, run lengths)
+    k = n // 3
+    x[:k] = (rng.standard_normal(k) * 10.0 ** rng.uniform(-6, 6, k)).astype(np.float32)
+    special = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1.4e-45, -1.4e-45, 1e-40, 3.4e38, -3.4e38, 2.0 ** -30, 2.0 ** 30,
+                        np.nextafter(np.float32(2.0 ** -30), np.float32(0)), np.nextafter(np.float32(2.0 ** 30), np.float32(np.inf)),
+                        2147483648.0, -2147483648.0, 2147483520.0, -2147483904.0, 0.5, -0.5, 1.9999999, 16777216.0, 65535.0, 0.499, 16385.6],
+                       dtype=np.float32)
+    x[k:k + special.size] = special
+    return x
+
+
+def test_short_division_is_ieee_division(contexts):
+    """quot_safe / recip_safe (the division without v_div_scale / v_div_fmas / v_div_fixup that the side-face and frustum blocks use
+    for operands in [2^-30, 2^30]) against IEEE division on 2^28 operand pairs -- random bit patterns, renderer-range values, all
+    specials, all-ones mantissas (the hard case of a Newton-refined reciprocal) -- and the helpers' other contracts."""
+    ctx = contexts("proc256", 320, 200)
+    rng = np.random.default_rng(2026)
+    n = 1 << 24
+    hard = ((rng.integers(0, 254, 4096).astype(np.uint32) << 23) | np.uint32(0x7FFFFF)).view(np.float32)  # 1.11...1 x 2^e
+    for chunk in range(16):
+        a, b = _float_soup(rng, n), _float_soup(rng, n)
+        if chunk % 2 == 0:  # both operands inside the short form's range: it is the path under test
+            a = (rng.uniform(-1, 1, n) * 2.0 ** rng.uniform(-30, 30, n)).astype(np.float32)
+            b = (rng.uniform(-1, 1, n) * 2.0 ** rng.uniform(-30, 30, n)).astype(np.float32)
+        b[-4096:] = hard * np.float32(2.0 ** -100) if chunk < 8 else hard
+        a[-8192:-4096] = hard
+        with np.errstate(all="ignore"):
+            want = (a / b).view(np.uint32)
+            got = ctx.selftest_math(10, a, b).view(np.uint32)
+            nan = np.isnan(a / b)
+            assert np.array_equal(got[~nan], want[~nan]) and np.isnan(got.view(np.float32)[nan]).all(), f"chunk {chunk}: {(got != want).sum()} quotients differ"
+            want = (np.float32(1.0) / b).view(np.uint32)
+            got = ctx.selftest_math(11, a, b).view(np.uint32)
+            nan = np.isnan(b)
+            assert np.array_equal(got[~nan], want[~nan]), f"chunk {chunk}: reciprocals differ"
+    a, b = _float_soup(rng, 1 << 20), _float_soup(rng, 1 << 20)
+    with np.errstate(all="ignore"):
+        # f2i_floor == (int)floorf with the x86 rule
+        fl = np.floor(a)
+        oor = np.isnan(fl) | (fl >= np.float32(2147483648.0)) | (fl < np.float32(-2147483648.0))
+        want = np.where(oor, np.int64(-2147483648), np.where(oor, 0, fl).astype(np.int64)).astype(np.int32)
+        assert np.array_equal(ctx.selftest_math(12, a, b).view(np.int32), want)
+        # v_min_f32 / v_max_f32 == Unity's min / max except for the sign of a zero result and NaN payloads
+        for op, ref in ((13, lambda x, y: np.where(np.isnan(y) | (x < y), x, y)), (14, lambda x, y: np.where(np.isnan(y) | (x > y), x, y))):
+            got, want = ctx.selftest_math(op, a, b), ref(a, b)
+            same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want)) | ((got == 0) & (want == 0))
+            # (a SIGNALLING NaN operand comes back quieted instead of being dropped; arithmetic never produces one and the
+            # library rejects non-finite inputs, so the kernel cannot meet one)
+            snan = lambda v: np.isnan(v) & ((v.view(np.uint32) & np.uint32(0x00400000)) == 0)
+            assert (same | snan(a) | snan(b)).all()
+        # div_safe: magnitude in [2^-30, 2^30]
+        mag = np.abs(a)
+        assert np.array_equal(ctx.selftest_math(15, a, b) == 1.0, (mag >= np.float32(2.0 ** -30)) & (mag <= np.float32(2.0 ** 30)))
+
+
 def test_errors_are_reported_not_swallowed():
     ctx = gpu.Context(0)
     ws = scenes.load_world("proc256")
