@@ -1,46 +1,50 @@
 // cvx_device.h -- device-side data layout of libcpuvox_gpu (gfx950 only).
 //
-// World: per LOD and per walk direction a dense array of 32-byte column
-// records (x-major, index (x>>lod)*(dimZ>>lod) + (z>>lod) like
-// World.GetIndexKnownInBounds, World.cs:145-149) built on upload from the
-// reference's 12-byte headers (World.cs:161-169), plus the element pool in the
-// reference's own order [guard][run 0..n-1][guard][colour 0..s-1]
-// (World.cs:163-165), from which the kernel reads the colours.
+// World: ONE arena for all six LODs.  Per LOD a table of 32-byte column records in 8 x 8 tiles (a DDA step to a
+// neighbouring column stays inside a 2 KB tile most of the time; World.GetIndexKnownInBounds' x-major order, World.cs:
+// 145-149, puts x-neighbours dimZ * 32 bytes apart), built on upload from the reference's 12-byte headers (World.cs:161-169),
+// an overflow list of solid runs for the few columns with more than two, and the element pool in the reference's own
+// order [guard][run 0..n-1][guard][colour 0..s-1] (World.cs:163-165), from which the kernel reads the colours.  Everything
+// is addressed with 32-bit byte offsets from the arena base (one scalar register pair for the whole wave; the arena is
+// limited to 4 GiB).
 //
-// Raybuffer: tile-major.  A tile is 64 consecutive rays of one segment (one
-// wavefront); inside a tile pixel y of lane l lives at (y*64 + l), so a wave
-// storing the same pixel row writes 256 contiguous bytes.  Tiles of segment 0
-// then segment 1 fill the top-down pool, 2 then 3 the left-right pool.  The
-// reference's ray-major rows (RayBuffer.cs:121-128) are reconstructed on
-// read-back / in the blit.
+// Raybuffer: tile-major.  A tile is 64 consecutive rays of one segment (one wavefront); inside a tile pixel y of lane l
+// lives at (y*64 + l), so a wave storing the same pixel row writes 256 contiguous bytes.  Tiles of segment 0 then
+// segment 1 fill the top-down pool, 2 then 3 the left-right pool.  The reference's ray-major rows (RayBuffer.cs:121-128)
+// are reconstructed on read-back / in the blit.
 #pragma once
 
 #include <stdint.h>
 
 #define CVX_WAVE 64
 #define CVX_SKYBOX_ARGB 0x191919FFu /* ColorARGB32(25,25,25): bytes FF 19 19 19 (DrawSegmentRayJob.cs:702) */
+#define CVX_TILE_SHIFT 3            /* column records are stored in tiles of 8 x 8 columns */
 
 struct DevWorldLevel {
-	// 32-byte column records, one table per element iteration direction (ITERATION_DIRECTION +1 walks a column
-	// top-down, -1 bottom-up).  The reference walks every RLE element (air runs only move the bounds, World.cs:245-259);
-	// the records hold the SOLID runs only, in walk order, with the position the walk would have reached:
+	// One 32-byte record per column.  The reference walks every RLE element of a column (air runs only move the bounds,
+	// World.cs:245-259), from the top down (ITERATION_DIRECTION +1) or from the bottom up (-1); the record holds the SOLID
+	// runs only, top-down, each with its distance from the top of the column -- upload checks that the runs of a column add up
+	// to the column height (the reference's builder always emits such columns, WordBuilder.cs:232-258), so the same numbers
+	// give the positions the bottom-up walk accumulates, and one table serves both directions (the kernel walks it backwards):
 	//   [0] = {colorsBase, solidCount | worldMin << 16, worldMax | runCount << 16, overflowBase}
-	//         colorsBase   = pool index of the column's first colour (RLEColumn.ColorPointer, World.cs:185)
-	//         overflowBase = index into runsDown / runsUp of solid run 2 (valid when solidCount > 2; even = 16-byte aligned)
-	//   [1] = solid runs 0 and 1, two words each:
-	//         w0 = start | length << 16   start = voxels (of this LOD) between the walk's starting end of the column and the run
-	//         w1 = colorsIndex | elementIndex << 16   elementIndex = 1-based position of the run among ALL elements in walk order
+	//         colorsBase   = element index (inside this level's pool) of the column's first colour (RLEColumn.ColorPointer, World.cs:185)
+	//         overflowBase = index into this level's run list of solid run 2 (valid when solidCount > 2)
+	//   [1] = solid runs 0 and 1 (top-down order), two words each:
+	//         w0 = start | length << 16      start = voxels (of this LOD) between the top of the column and the run
+	//         w1 = colorsIndex | elementIndex << 16   elementIndex = 1-based position of the run among ALL elements, top-down
 	//              (only the counting variant reads it: it restores the reference's element count E)
-	const uint4 *columnsDown;
-	const uint4 *columnsUp;
-	const uint2 *runsDown; // solid runs 2.. of the columns that have more than two
-	const uint2 *runsUp;
-	const uint32_t *elements; // the reference's element pool (RLEElement / ColorARGB32); the kernel reads colours only
-	int32_t shift;            // lod
-	int32_t mulX;             // dimZ >> lod
+	// Record of column (x, z) (LOD-0 coordinates): cx = x >> shift, cz = z >> shift;
+	//   index = ((cx >> 3 << tilesZShift) + (cz >> 3)) * 64 + (cx & 7) * 8 + (cz & 7)
+	uint32_t recordsOff;  // byte offsets from DevWorld::arena
+	uint32_t runsOff;     // uint2 per solid run k >= 2
+	uint32_t elementsOff; // the reference's element pool (RLEElement / ColorARGB32); the kernel reads colours only
+	int32_t shift;        // lod
+	int32_t tilesZShift;  // log2 of the number of 8-column tiles along z
+	int32_t pad_;
 };
 
 struct DevWorld {
+	const uint8_t *arena;
 	DevWorldLevel level[6];
 	int32_t dimX, dimY, dimZ;
 	int32_t maskX, maskZ; // dimensionMaskXZ, World.cs:23

@@ -281,6 +281,60 @@ int SyncWorld(cvx_context *ctx)
 				return Fail(ctx, CVX_ERR_NOT_READY, "world LOD %d has not been uploaded (UnityManager.LOD_LEVELS = 6)", i);
 			}
 		}
+		// One arena for all levels: [records | run list | element pool] per level, 256-byte aligned parts, 32-bit offsets.
+		DevWorld next = ctx->hostWorld;
+		size_t cursor = 0;
+		auto place = [&](size_t bytes) { const size_t at = cursor; cursor = (cursor + bytes + 255) & ~(size_t)255; return at; };
+		size_t recordsAt[CVX_LOD_LEVELS], runsAt[CVX_LOD_LEVELS], elementsAt[CVX_LOD_LEVELS];
+		for (int i = 0; i < CVX_LOD_LEVELS; i++) {
+			const cvx_context::HostLevel &H = ctx->hostLevel[i];
+			recordsAt[i] = place(H.recordsBytes);
+			runsAt[i] = place(H.runsBytes);
+			elementsAt[i] = place(H.elementsBytes);
+		}
+		if (cursor >= ((size_t)1 << 32)) {
+			return Fail(ctx, CVX_ERR_CAPACITY, "the world needs %.2f GiB of device tables: more than the 4 GiB the 32-bit offsets of the kernel can address", (double)cursor / (double)((size_t)1 << 30));
+		}
+		CVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		uint8_t *arena = nullptr;
+		CVX_HIP(ctx, hipMalloc((void **)&arena, cursor));
+		hipError_t e = hipSuccess;
+		for (int i = 0; i < CVX_LOD_LEVELS && e == hipSuccess; i++) {
+			cvx_context::HostLevel &H = ctx->hostLevel[i];
+			if (H.pending) {
+				e = hipMemcpy(arena + recordsAt[i], H.records.data(), H.recordsBytes, hipMemcpyHostToDevice);
+				if (e == hipSuccess) { e = hipMemcpy(arena + runsAt[i], H.runs.data(), H.runsBytes, hipMemcpyHostToDevice); }
+				if (e == hipSuccess) { e = hipMemcpy(arena + elementsAt[i], H.elements.data(), H.elementsBytes, hipMemcpyHostToDevice); }
+			} else { // unchanged level: it lives in the old arena
+				const DevWorldLevel &old = ctx->hostWorld.level[i];
+				e = hipMemcpy(arena + recordsAt[i], ctx->arena + old.recordsOff, H.recordsBytes, hipMemcpyDeviceToDevice);
+				if (e == hipSuccess) { e = hipMemcpy(arena + runsAt[i], ctx->arena + old.runsOff, H.runsBytes, hipMemcpyDeviceToDevice); }
+				if (e == hipSuccess) { e = hipMemcpy(arena + elementsAt[i], ctx->arena + old.elementsOff - 16, H.elementsBytes, hipMemcpyDeviceToDevice); }
+			}
+		}
+		if (e != hipSuccess) {
+			(void)hipFree(arena);
+			return Fail(ctx, CVX_ERR_HIP, "world upload failed: %s", hipGetErrorString(e));
+		}
+		for (int i = 0; i < CVX_LOD_LEVELS; i++) {
+			cvx_context::HostLevel &H = ctx->hostLevel[i];
+			std::vector<uint4>().swap(H.records);
+			std::vector<uint2>().swap(H.runs);
+			std::vector<uint32_t>().swap(H.elements);
+			H.pending = false;
+			DevWorldLevel &L = next.level[i];
+			L.recordsOff = (uint32_t)recordsAt[i];
+			L.runsOff = (uint32_t)runsAt[i];
+			L.elementsOff = (uint32_t)(elementsAt[i] + 16); // past the leading guard entries (kPoolPad * 4 bytes)
+			L.shift = i;
+			L.tilesZShift = H.tilesZShift;
+			L.pad_ = 0;
+		}
+		if (ctx->arena) { (void)hipFree(ctx->arena); }
+		ctx->arena = arena;
+		ctx->arenaBytes = cursor;
+		next.arena = arena;
+		ctx->hostWorld = next;
 		if (!ctx->devWorld) {
 			CVX_HIP(ctx, hipMalloc((void **)&ctx->devWorld, sizeof(DevWorld)));
 		}
@@ -404,10 +458,7 @@ void cvx_destroy(cvx_context *ctx)
 	(void)hipSetDevice(ctx->device);
 	if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
 	FreeRaybuffers(ctx);
-	for (int i = 0; i < CVX_LOD_LEVELS; i++) {
-		if (ctx->levelHeaders[i]) { (void)hipFree(ctx->levelHeaders[i]); }
-		if (ctx->levelElements[i]) { (void)hipFree(ctx->levelElements[i]); }
-	}
+	if (ctx->arena) { (void)hipFree(ctx->arena); }
 	if (ctx->devWorld) { (void)hipFree(ctx->devWorld); }
 	if (ctx->devFrames) { (void)hipFree(ctx->devFrames); }
 	if (ctx->devTiles) { (void)hipFree(ctx->devTiles); }

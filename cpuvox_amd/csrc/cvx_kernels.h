@@ -35,12 +35,23 @@ namespace cvxk {
 #endif
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4))); // (HIP's uint4 / uint2 classes cannot be copied out of a qualified address space)
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-typedef const CVX_GLOBAL u32x4 *gptr_u4;
-typedef const CVX_GLOBAL u32x2 *gptr_u2;
-typedef const CVX_GLOBAL uint32_t *gptr_u32;
+typedef const CVX_GLOBAL uint8_t *gptr_arena;
 typedef CVX_GLOBAL uint32_t *gptr_out;
-__device__ __forceinline__ uint4 ld4(gptr_u4 p) { const u32x4 v = *p; return uint4{ v.x, v.y, v.z, v.w }; }
-__device__ __forceinline__ uint2 ld2(gptr_u2 p) { const u32x2 v = *p; return uint2{ v.x, v.y }; }
+// World data: wave-uniform arena base (a scalar register pair) + 32-bit per-lane byte offset -- the "saddr" form of the
+// global_load instructions; a per-lane 64-bit pointer would cost two vector registers for every table the column loop touches.
+__device__ __forceinline__ uint4 ld4(gptr_arena arena, uint32_t byteOff) { const u32x4 v = *(const CVX_GLOBAL u32x4 *)(arena + byteOff); return uint4{ v.x, v.y, v.z, v.w }; }
+__device__ __forceinline__ uint2 ld2(gptr_arena arena, uint32_t byteOff) { const u32x2 v = *(const CVX_GLOBAL u32x2 *)(arena + byteOff); return uint2{ v.x, v.y }; }
+__device__ __forceinline__ uint32_t ld1(gptr_arena arena, uint32_t byteOff) { return *(const CVX_GLOBAL uint32_t *)(arena + byteOff); }
+// Raybuffer tile: wave-uniform tile base + 32-bit byte offset (pixel row y of the lane's column: y * 256 + lane * 4)
+typedef CVX_GLOBAL uint8_t *gptr_tile;
+__device__ __forceinline__ void st_pixel(gptr_tile tile, uint32_t laneByteOff, int y, uint32_t argb) { *(CVX_GLOBAL uint32_t *)(tile + ((uint32_t)y * (CVX_WAVE * 4u) + laneByteOff)) = argb; }
+
+// Byte offset (inside the level's table) of the 32-byte record of LOD column (cx, cz): 8 x 8 tiles, cvx_device.h
+__device__ __forceinline__ uint32_t record_offset(int cx, int cz, int tilesZShift)
+{
+	const uint32_t tile = ((uint32_t)(cx >> CVX_TILE_SHIFT) << tilesZShift) + (uint32_t)(cz >> CVX_TILE_SHIFT);
+	return (((tile << 6) + ((uint32_t)(cx & 7) << 3) + (uint32_t)(cz & 7))) << 5;
+}
 
 // ---- Unity.Mathematics scalar semantics (math.cs 1.2.6) --------------------
 __device__ __forceinline__ float m_min(float x, float y) { return (y != y || x < y) ? x : y; }
@@ -386,7 +397,7 @@ struct LaneCounters {
 // ---------------------------------------------------------------------------
 template <int DIR, bool COUNT>
 __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S, const DevWorld *__restrict__ world, int planeRayIndex,
-                                          uint32_t *seen /* &lds[lane] */, int sshift /* log2 of the mask word stride */, gptr_out out /* tile + lane */, LaneCounters &cnt, ProfLane &prof)
+                                          uint32_t *seen /* &lds[lane] */, int sshift /* log2 of the mask word stride */, gptr_tile tileOut, uint32_t laneByteOff, LaneCounters &cnt, ProfLane &prof)
 {
 	(void)prof;
 	const int omin = S.omin, omax = S.omax;
@@ -426,6 +437,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 	// ---- ExecuteRay, :195-620
 	int voxelScale = 1 << lod;
 	DevWorldLevel L = world->level[lod];
+	const gptr_arena arena = (gptr_arena)world->arena;
 	const int maskX = world->maskX, maskZ = world->maskZ;
 	const int worldMaxYInt = world->dimY;
 	const float worldMaxY = (float)worldMaxYInt;
@@ -468,9 +480,10 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 	uint4 header, queue;              // record of the current column: header + its first two solid runs in walk order
 	float curDistLast, curDistNext;   // ray.IntersectionDistances of the current column
 	int curScale;                     // voxelScale of the current column
-	gptr_u32 curElements;             // element pool of the current column's LOD (colours)
-	gptr_u2 curRuns;                  // overflow list (solid runs 2..) of the current column's LOD and walk direction
-	uint4 ext = { 0u, 0u, 0u, 0u };   // solid runs 2 and 3 of the current column (columns with more than two)
+	uint32_t curElementsOff;          // element pool of the current column's LOD (colours): byte offset in the arena
+	uint32_t curRunsOff;              // run list (solid runs 2..) of the current column's LOD
+	uint4 ext = { 0u, 0u, 0u, 0u };   // the first two entries of the current column's run list the walk will need (columns with more than two solid runs)
+	int extFirst = 0;                 // their position in the column's list: 0 (top-down walk) or max(0, solidCount - 4) (bottom-up)
 	unsigned int consumed = 0u;       // counting variant: elements the reference's walk has dereferenced in this column
 	float worldBoundsMin, worldBoundsMax;
 
@@ -480,7 +493,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		const int solidCount = (int)(header.y & 0xFFFFu);
 		CVX_BEGIN();
 		if (COUNT) { consumed = 0u; }
-		const gptr_u2 overflowRuns = curRuns + header.w - 2; // solid run k >= 2 lives at overflowRuns[k]
+		const uint32_t columnRunsOff = curRunsOff + header.w * 8u; // solid run j >= 2 (top-down numbering) lives at entry j - 2
 		// :289-293
 		const f3 camSpaceMinLast = f3_madd(planeStartBottom, planeDir, curDistLast);
 		const f3 camSpaceMinNext = f3_madd(planeStartBottom, planeDir, curDistNext);
@@ -549,7 +562,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		// bounds the reference accumulates are exactly these integers), so only solid runs are iterated here.
 		float elementBoundsMin, elementBoundsMax;
 		int solidIndex = 0;
-		const gptr_u32 worldColumnColors = curElements + header.x; // ColorPointer, World.cs:185
+		const uint32_t worldColumnColorsOff = curElementsOff + header.x * 4u; // ColorPointer, World.cs:185
 
 		// Element loop :441-611, realigned for SIMT: every lane first walks its own elements (cheap: decode,
 		// bounds bookkeeping, air / world-bounds culls :445-475) up to its next run that has to be projected;
@@ -562,30 +575,29 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			CVX_BEGIN();
 			while (solidIndex < solidCount) {
 				CVX_COUNT(3);
+				// the walk's k-th solid run is run k of the record's top-down list, or run solidCount - 1 - k for the bottom-up walk
+				const int j = DIR > 0 ? solidIndex : solidCount - 1 - solidIndex;
 				uint32_t w0, w1;
-				if (solidIndex < 4) {
-					const bool odd = (solidIndex & 1) != 0;
-					const uint4 pair = solidIndex < 2 ? queue : ext;
+				const int rel = j - 2 - extFirst;
+				if (j < 2 || (rel == 0 || rel == 1)) {
+					const bool odd = j < 2 ? (j & 1) != 0 : rel != 0;
+					const uint4 pair = j < 2 ? queue : ext;
 					w0 = odd ? pair.z : pair.x;
 					w1 = odd ? pair.w : pair.y;
 				} else {
-					const uint2 run = ld2(overflowRuns + solidIndex);
+					const uint2 run = ld2(arena, columnRunsOff + (uint32_t)(j - 2) * 8u);
 					w0 = run.x;
 					w1 = run.y;
 				}
 				solidIndex++;
 				elementLength = (int)(w0 >> 16);
 				elementColorsIndex = (int)(w1 & 0xFFFFu);
-				if (COUNT) { consumed = w1 >> 16; }
-				const int walked = (int)(w0 & 0xFFFFu) * curScale;
-				if (DIR > 0) {
-					const int top = worldMaxYInt - walked;
-					elementBoundsMax = (float)top;
-					elementBoundsMin = (float)(top - elementLength * curScale);
-				} else {
-					elementBoundsMin = (float)walked;
-					elementBoundsMax = (float)(walked + elementLength * curScale);
-				}
+				if (COUNT) { consumed = DIR > 0 ? (w1 >> 16) : (header.z >> 16) + 1u - (w1 >> 16); } // position among all elements in walk order
+				// The run's world-space span.  Top-down the reference accumulates it from worldMaxY (:429-431,449-451), bottom-up from 0
+				// (:433-435,453-455): integer sums either way, and the runs of a column add up to its height, so both are these.
+				const int top = worldMaxYInt - (int)(w0 & 0xFFFFu) * curScale;
+				elementBoundsMax = (float)top;
+				elementBoundsMin = (float)(top - elementLength * curScale);
 				if (elementBoundsMin > worldBoundsMax) {
 					if (DIR < 0) { solidIndex = solidCount + 1; break; } else { continue; }
 				}
@@ -616,7 +628,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			const bool faceWanted = faceTop ? !(elementBoundsMax > worldBoundsMax) : (faceBottom && !(elementBoundsMin < worldBoundsMin));
 			uint32_t secondaryColor = 0u;
 			if (faceWanted) {
-				secondaryColor = worldColumnColors[faceTop ? elementColorsIndex : elementColorsIndex + elementLength - 1];
+				secondaryColor = ld1(arena, worldColumnColorsOff + (uint32_t)(faceTop ? elementColorsIndex : elementColorsIndex + elementLength - 1) * 4u);
 			}
 
 			// side of the run, :484-542
@@ -698,7 +710,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 									float wuy = m_lerp(uvAy, uvBy, l);
 									float u = wuy / wux;
 									int colorIdx = m_clampi(f2i_floor(u), 0, elementLength - 1) + elementColorsIndex;
-									out[y * CVX_WAVE] = worldColumnColors[colorIdx];
+									st_pixel(tileOut, laneByteOff, y, ld1(arena, worldColumnColorsOff + (uint32_t)colorIdx * 4u));
 									if (COUNT) { cnt.C++; cnt.P++; }
 								} while (todo != 0u);
 							}
@@ -763,7 +775,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 								CVX_COUNT(7);
 								const int y = (w << 5) + (__ffs((int)todo) - 1);
 								todo &= todo - 1u;
-								out[y * CVX_WAVE] = secondaryColor;
+								st_pixel(tileOut, laneByteOff, y, secondaryColor);
 								if (COUNT) { cnt.P++; }
 							} while (todo != 0u);
 						}
@@ -779,25 +791,21 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		return true;
 	};
 
-	gptr_u4 table = (gptr_u4)(DIR > 0 ? L.columnsDown : L.columnsUp);
-
 	// column 0: LOD check (:237-243), bounds test and fetch (World.GetVoxelColumn, World.cs:130-142)
 	if (ray.distLast >= lodMax && lod < 5) {
 		dda_next_lod(ray, voxelScale, dirXNonNegative, dirZNonNegative);
 		lod++;
 		voxelScale *= 2;
 		L = world->level[lod];
-		table = (gptr_u4)(DIR > 0 ? L.columnsDown : L.columnsUp);
 		lodMax = F.lod[lod];
 	}
 	if ((ray.px & maskX) != ray.px || (ray.pz & maskZ) != ray.pz) {
 		return; // out of world bounds -> WriteSkybox
 	}
 	{
-		const size_t column = (size_t)((ray.px >> L.shift) * L.mulX + (ray.pz >> L.shift));
-		const gptr_u4 rec = table + 2 * column;
-		header = ld4(rec);
-		queue = ld4(rec + 1);
+		const uint32_t rec = L.recordsOff + record_offset(ray.px >> L.shift, ray.pz >> L.shift, L.tilesZShift);
+		header = ld4(arena, rec);
+		queue = ld4(arena, rec + 16u);
 	}
 
 	while (true) {
@@ -811,13 +819,17 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		curDistLast = ray.distLast;
 		curDistNext = ray.distNext;
 		curScale = voxelScale;
-		curElements = (gptr_u32)L.elements;
-		curRuns = (gptr_u2)(DIR > 0 ? L.runsDown : L.runsUp);
+		curElementsOff = L.elementsOff;
+		curRunsOff = L.runsOff;
 		const int curLod = lod;
-		// Runs 2 and 3 of the current column (3 % of the columns have them) are requested BEFORE the look-ahead record: vector
-		// memory returns in order, so the element walk can wait for them (vmcnt(2)) and leave the look-ahead in flight.
+		// The first two run-list entries the walk needs (3 % of the columns have more than two solid runs) are requested BEFORE the
+		// look-ahead record: vector memory returns in order, so the element walk can wait for them and leave the look-ahead in flight.
 		if ((header.y & 0xFFFFu) > 2u) {
-			ext = ld4((gptr_u4)(curRuns + header.w));
+			const int solids = (int)(header.y & 0xFFFFu);
+			extFirst = DIR > 0 ? 0 : max(0, solids - 4);
+			const uint32_t at = curRunsOff + (header.w + (uint32_t)extFirst) * 8u;
+			const uint2 e0 = ld2(arena, at), e1 = ld2(arena, at + 8u);
+			ext = uint4{ e0.x, e0.y, e1.x, e1.y };
 		}
 		const bool lastColumn = dda_step(ray, farClip); // true: far clip reached after this column
 		// (the LOD check and the fetch are done for every lane, also one that stops after this column: its state is
@@ -827,14 +839,12 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			lod++;
 			voxelScale *= 2;
 			L = world->level[lod];
-			table = (gptr_u4)(DIR > 0 ? L.columnsDown : L.columnsUp);
 			lodMax = F.lod[lod];
 		}
 		const bool nextOutside = (ray.px & maskX) != ray.px || (ray.pz & maskZ) != ray.pz;
-		const size_t column = (size_t)(((ray.px & maskX) >> L.shift) * L.mulX + ((ray.pz & maskZ) >> L.shift)); // clamped into the table
-		const gptr_u4 rec = table + 2 * column;
-		const uint4 nextHeader = ld4(rec);
-		const uint4 nextQueue = ld4(rec + 1);
+		const uint32_t rec = L.recordsOff + record_offset((ray.px & maskX) >> L.shift, (ray.pz & maskZ) >> L.shift, L.tilesZShift); // clamped into the table
+		const uint4 nextHeader = ld4(arena, rec);
+		const uint4 nextQueue = ld4(arena, rec + 16u);
 
 		// ---- the current column, exactly as the reference processes it
 		if (COUNT) {
@@ -915,7 +925,8 @@ __global__ __launch_bounds__(CVX_WAVE, CVX_WAVES_PER_SIMD) void render_kernel(co
 			lds[(w << sshift) + lane] = 0u; // stackalloc is zero-initialised, :208
 		}
 	}
-	const gptr_out out = (gptr_out)tile.out + firstLane + lane;
+	const gptr_tile tileOut = (gptr_tile)tile.out;
+	const uint32_t laneByteOff = (uint32_t)(firstLane + lane) * 4u;
 	uint32_t *seen = lds + lane - (wordBase << sshift);
 	ProfLane prof;
 #ifdef CVX_PROFILE_SECTIONS
@@ -935,9 +946,9 @@ __global__ __launch_bounds__(CVX_WAVE, CVX_WAVES_PER_SIMD) void render_kernel(co
 	if (active) {
 		// RenderJob.Execute :174-178: the iteration direction is a per-frame (wave-uniform) constant
 		if (F.inverse) {
-			trace_ray<-1, COUNT>(F, S, world, planeRayIndex, seen, sshift, out, cnt, prof);
+			trace_ray<-1, COUNT>(F, S, world, planeRayIndex, seen, sshift, tileOut, laneByteOff, cnt, prof);
 		} else {
-			trace_ray<1, COUNT>(F, S, world, planeRayIndex, seen, sshift, out, cnt, prof);
+			trace_ray<1, COUNT>(F, S, world, planeRayIndex, seen, sshift, tileOut, laneByteOff, cnt, prof);
 		}
 	}
 
@@ -952,7 +963,7 @@ __global__ __launch_bounds__(CVX_WAVE, CVX_WAVES_PER_SIMD) void render_kernel(co
 #pragma unroll 4
 		for (int b = 0; b < 32; b++) {
 			if ((todo >> b) & 1u) {
-				out[(base + b) * CVX_WAVE] = CVX_SKYBOX_ARGB;
+				st_pixel(tileOut, laneByteOff, base + b, CVX_SKYBOX_ARGB);
 			}
 		}
 		if (COUNT) { skyPixels += (unsigned int)__popc(todo); }

@@ -44,8 +44,10 @@ int ValidateColumn(cvx_context *ctx, int64_t i, const RefHeader &h, const uint32
 			if (colorsIndex + length > colours) { colours = colorsIndex + length; }
 		}
 	}
-	if (total > maxY || off + h.runCount + 2 + colours > elementCount) {
-		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "column %lld: runs exceed the world height or colours exceed the pool", (long long)i);
+	if (total != maxY || off + h.runCount + 2 + colours > elementCount) {
+		// (total == height: RLEColumnBuilder.ToFinalColumn always emits full-height columns, WordBuilder.cs:232-258; for a shorter
+		// one the reference's top-down and bottom-up walks would place the same run at different heights)
+		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "column %lld: runs do not add up to the column height or colours exceed the pool", (long long)i);
 	}
 	*solidRuns = solid;
 	return CVX_OK;
@@ -75,12 +77,14 @@ int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byt
 	const RefHeader *src = static_cast<const RefHeader *>(storage);
 	const uint32_t *elements = reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(storage) + (size_t)columnCount * 12);
 
-	// Validate every column (so that nothing the kernel dereferences can leave the pool) and build the two tables of
-	// 32-byte solid-run records plus the two overflow lists (cvx_device.h).
-	const size_t columnsAlloc = (size_t)(usedColumns > 0 ? usedColumns : 1);
-	const size_t tableEntries = columnsAlloc * 2;
+	// Validate every column (so that nothing the kernel dereferences can leave the pool) and build the table of 32-byte
+	// solid-run records (8 x 8 tiles) plus the overflow list (cvx_device.h).  The data goes to the device with the next draw.
 	const int maxY = dimY >> lod;
-	size_t overflowEntries = 2; // never empty: keeps the pointers valid
+	const int64_t tilesX = (usedX + 7) >> 3, tilesZ = (usedZ + 7) >> 3;
+	int tilesZShift = 0;
+	while (((int64_t)1 << tilesZShift) < tilesZ) { tilesZShift++; }
+	const size_t recordCount = (size_t)tilesX * ((size_t)1 << tilesZShift) * 64u;
+	size_t overflowEntries = 2; // never empty; the kernel may read two entries at any overflowBase
 	for (int64_t i = 0; i < usedColumns; i++) {
 		const RefHeader &h = src[i];
 		if (h.runCount == 0) {
@@ -92,81 +96,61 @@ int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byt
 			return rc;
 		}
 		if (solid > 2) {
-			overflowEntries += (solid - 2 + 1) & ~(size_t)1; // lists start 16-byte aligned
+			overflowEntries += solid - 2;
 		}
 	}
-	std::vector<uint4> headers(tableEntries * 2, uint4{ 0u, 0u, 0u, 0u });
-	std::vector<uint2> overflow(overflowEntries * 2, uint2{ 0u, 0u }); // down list, then up list
+	cvx_context::HostLevel &H = ctx->hostLevel[lod];
+	H.records.assign(recordCount * 2, uint4{ 0u, 0u, 0u, 0u });
+	H.runs.assign(overflowEntries + 2, uint2{ 0u, 0u });
 	size_t overflowCursor = 0;
-	std::vector<uint2> walk;
-	for (int64_t i = 0; i < usedColumns; i++) {
-		const RefHeader &h = src[i];
-		if (h.runCount == 0) {
-			continue;
-		}
-		const int64_t off = h.storageOffset;
-		const int n = h.runCount;
-		size_t solid = 0;
-		for (int r = 0; r < n; r++) {
-			solid += (int16_t)(elements[off + 1 + r] & 0xFFFFu) >= 0 ? 1u : 0u;
-		}
-		const size_t listBase = overflowCursor;
-		for (int dir = 0; dir < 2; dir++) { // 0: top-down (ITERATION_DIRECTION +1), 1: bottom-up
-			walk.clear();
-			uint32_t start = 0;
-			for (int k = 0; k < n; k++) {
-				const int r = dir == 0 ? k : n - 1 - k;
+	for (int64_t cx = 0; cx < usedX; cx++) {
+		for (int64_t cz = 0; cz < usedZ; cz++) {
+			const int64_t i = cx * usedZ + cz; // World.GetIndexKnownInBounds, World.cs:145-149
+			const RefHeader &h = src[i];
+			if (h.runCount == 0) {
+				continue;
+			}
+			const int64_t off = h.storageOffset;
+			const int n = h.runCount;
+			uint4 *rec = H.records.data() + 2 * ((size_t)(((cx >> 3) << tilesZShift) + (cz >> 3)) * 64u + (size_t)((cx & 7) * 8 + (cz & 7)));
+			uint32_t start = 0, solid = 0;
+			const size_t listBase = overflowCursor;
+			uint2 first[2] = { uint2{ 0u, 0u }, uint2{ 0u, 0u } };
+			for (int r = 0; r < n; r++) { // top-down
 				const uint32_t raw = elements[off + 1 + r];
 				const uint32_t length = raw >> 16;
 				if ((int16_t)(raw & 0xFFFFu) >= 0) {
-					walk.push_back(uint2{ start | (length << 16), (raw & 0xFFFFu) | ((uint32_t)(k + 1) << 16) });
+					const uint2 run = uint2{ start | (length << 16), (raw & 0xFFFFu) | ((uint32_t)(r + 1) << 16) };
+					if (solid < 2) {
+						first[solid] = run;
+					} else {
+						H.runs[overflowCursor++] = run;
+					}
+					solid++;
 				}
 				start += length;
 			}
-			uint4 *rec = headers.data() + (dir == 0 ? 0 : tableEntries) + (size_t)i * 2;
-			rec[0] = uint4{ (uint32_t)(off + n + 2), (uint32_t)solid | ((uint32_t)h.worldMin << 16), (uint32_t)h.worldMax | ((uint32_t)n << 16), (uint32_t)listBase };
-			rec[1] = uint4{ solid > 0 ? walk[0].x : 0u, solid > 0 ? walk[0].y : 0u, solid > 1 ? walk[1].x : 0u, solid > 1 ? walk[1].y : 0u };
-			for (size_t k = 2; k < solid; k++) {
-				overflow[(dir == 0 ? 0 : overflowEntries) + listBase + (k - 2)] = walk[k];
-			}
-		}
-		if (solid > 2) {
-			overflowCursor += (solid - 2 + 1) & ~(size_t)1;
+			rec[0] = uint4{ (uint32_t)(off + n + 2), solid | ((uint32_t)h.worldMin << 16), (uint32_t)h.worldMax | ((uint32_t)n << 16), (uint32_t)listBase };
+			rec[1] = uint4{ first[0].x, first[0].y, first[1].x, first[1].y };
 		}
 	}
-
-	CVX_HIP(ctx, hipSetDevice(ctx->device));
-	CVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-	if (ctx->levelHeaders[lod]) { (void)hipFree(ctx->levelHeaders[lod]); ctx->levelHeaders[lod] = nullptr; }
-	if (ctx->levelElements[lod]) { (void)hipFree(ctx->levelElements[lod]); ctx->levelElements[lod] = nullptr; }
-	ctx->levelSet[lod] = false;
-	const size_t headerBytes = headers.size() * sizeof(uint4);
-	CVX_HIP(ctx, hipMalloc(&ctx->levelHeaders[lod], headerBytes + overflow.size() * sizeof(uint2)));
 	const size_t kPoolPad = 4; // zeroed guard entries around the pool
-	CVX_HIP(ctx, hipMalloc(&ctx->levelElements[lod], ((size_t)(elementCount > 0 ? elementCount : 0) + 2 * kPoolPad) * 4));
-	CVX_HIP(ctx, hipMemset(ctx->levelElements[lod], 0, ((size_t)(elementCount > 0 ? elementCount : 0) + 2 * kPoolPad) * 4));
-	CVX_HIP(ctx, hipMemcpy(ctx->levelHeaders[lod], headers.data(), headerBytes, hipMemcpyHostToDevice));
-	CVX_HIP(ctx, hipMemcpy(static_cast<uint8_t *>(ctx->levelHeaders[lod]) + headerBytes, overflow.data(), overflow.size() * sizeof(uint2), hipMemcpyHostToDevice));
+	H.elements.assign((size_t)(elementCount > 0 ? elementCount : 0) + 2 * kPoolPad, 0u);
 	if (elementCount > 0) {
-		CVX_HIP(ctx, hipMemcpy(static_cast<uint32_t *>(ctx->levelElements[lod]) + kPoolPad, elements, (size_t)elementCount * 4, hipMemcpyHostToDevice));
+		std::memcpy(H.elements.data() + kPoolPad, elements, (size_t)elementCount * 4);
 	}
-	DevWorldLevel &L = ctx->hostWorld.level[lod];
-	L.columnsDown = static_cast<const uint4 *>(ctx->levelHeaders[lod]);
-	L.columnsUp = L.columnsDown + tableEntries;
-	L.runsDown = reinterpret_cast<const uint2 *>(L.columnsDown + tableEntries * 2);
-	L.runsUp = L.runsDown + overflowEntries;
-	L.elements = static_cast<const uint32_t *>(ctx->levelElements[lod]) + kPoolPad;
-	L.shift = lod;
-	L.mulX = dimZ >> lod;
+	H.recordsBytes = H.records.size() * sizeof(uint4);
+	H.runsBytes = H.runs.size() * sizeof(uint2);
+	H.elementsBytes = H.elements.size() * sizeof(uint32_t);
+	H.tilesZShift = tilesZShift;
+	H.pending = true;
 	if (lod == 0) {
 		if (ctx->hostWorld.dimX != dimX || ctx->hostWorld.dimY != dimY || ctx->hostWorld.dimZ != dimZ) {
 			// a LOD 0 of other dimensions starts a new world: the tables of the old LOD 1..5 are indexed with the old
 			// dimensions and must not survive (the draw reports CVX_ERR_NOT_READY until all levels are uploaded again)
 			for (int l = 1; l < CVX_LOD_LEVELS; l++) {
-				if (ctx->levelHeaders[l]) { (void)hipFree(ctx->levelHeaders[l]); ctx->levelHeaders[l] = nullptr; }
-				if (ctx->levelElements[l]) { (void)hipFree(ctx->levelElements[l]); ctx->levelElements[l] = nullptr; }
+				ctx->hostLevel[l] = cvx_context::HostLevel();
 				ctx->levelSet[l] = false;
-				ctx->hostWorld.level[l] = DevWorldLevel{};
 			}
 		}
 		ctx->hostWorld.dimX = dimX;

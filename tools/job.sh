@@ -1,2 +1,3 @@
-mkdir -p gpurun_out/r2c
-bash tools/variants.sh "libcpuvox_gpu_base.so libcpuvox_gpu.so libcpuvox_gpu_o2.so libcpuvox_gpu_o3.so" --frames 512 2>&1 | tee gpurun_out/r2c/variants_latency1.txt
+mkdir -p gpurun_out/r2d
+timeout 1500 python3 -m pytest tests -x -q -m gpu 2>&1 | tail -5 | tee gpurun_out/r2d/gpu_tests.txt
+bash tools/variants.sh "libcpuvox_gpu_base.so libcpuvox_gpu.so" --frames 512 2>&1 | tee gpurun_out/r2d/variants_arena.txt
