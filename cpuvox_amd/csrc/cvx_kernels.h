@@ -45,6 +45,16 @@ __device__ __forceinline__ uint32_t ld1(gptr_arena arena, uint32_t byteOff) { re
 // Raybuffer tile: wave-uniform tile base + 32-bit byte offset (pixel row y of the lane's column: y * 256 + lane * 4)
 typedef CVX_GLOBAL uint8_t *gptr_tile;
 __device__ __forceinline__ void st_pixel(gptr_tile tile, uint32_t laneByteOff, int y, uint32_t argb) { *(CVX_GLOBAL uint32_t *)(tile + ((uint32_t)y * (CVX_WAVE * 4u) + laneByteOff)) = argb; }
+#ifdef CVX_EXP_NOSTORE /* timing experiment only (wrong pictures): what the pixel stores of the column loop cost */
+#define st_pixel_loop(tile, lane, y, argb) asm volatile("" ::"v"(argb), "v"(y))
+#else
+#define st_pixel_loop st_pixel
+#endif
+#ifdef CVX_EXP_NOCOLORLOAD /* timing experiment only: what the colour loads cost */
+#define ld_color(arena, off) (off)
+#else
+#define ld_color ld1
+#endif
 
 // Byte offset (inside the level's table) of the 32-byte record of LOD column (cx, cz): 8 x 8 tiles, cvx_device.h
 __device__ __forceinline__ uint32_t record_offset(int cx, int cz, int tilesZShift)
@@ -373,16 +383,20 @@ __device__ unsigned long long g_sectionHist[CVX_NSEC * 8];
 #define CVX_COUNT(n) do { prof.lanes[n]++; const unsigned long long b_ = __ballot(1); if ((int)(threadIdx.x & 63) == __ffsll((long long)b_) - 1) { prof.acc[n]++; atomicAdd(&g_sectionHist[(n) * 8 + (__popcll(b_) - 1) / 8], 1ull); } } while (0)
 #define CVX_BEGIN() ((void)0)
 #define CVX_END(n) ((void)0)
+#define CVX_WAITPROBE(n) ((void)0)
 #else
 #define CVX_COUNT(n) ((void)0)
 #define CVX_BEGIN() (prof.last = (unsigned int)__builtin_amdgcn_s_memtime())
 #define CVX_END(n) do { const unsigned int t_ = (unsigned int)__builtin_amdgcn_s_memtime(); prof.acc[n] += t_ - prof.last; prof.last = t_; } while (0)
+// drains the vector-memory queue and books the time it took under section n (how long the wave would wait for memory here)
+#define CVX_WAITPROBE(n) do { CVX_END(15); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); CVX_END(n); } while (0)
 #endif
 #else
 #define CVX_COUNT(n) ((void)0)
 struct ProfLane {};
 #define CVX_BEGIN() ((void)0)
 #define CVX_END(n) ((void)0)
+#define CVX_WAITPROBE(n) ((void)0)
 #endif
 
 struct LaneCounters {
@@ -573,6 +587,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			int elementColorsIndex = 0, elementLength = 0;
 			bool found = false;
 			CVX_BEGIN();
+			CVX_WAITPROBE(10);
 			while (solidIndex < solidCount) {
 				CVX_COUNT(3);
 				// the walk's k-th solid run is run k of the record's top-down list, or run solidCount - 1 - k for the bottom-up walk
@@ -628,7 +643,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			const bool faceWanted = faceTop ? !(elementBoundsMax > worldBoundsMax) : (faceBottom && !(elementBoundsMin < worldBoundsMin));
 			uint32_t secondaryColor = 0u;
 			if (faceWanted) {
-				secondaryColor = ld1(arena, worldColumnColorsOff + (uint32_t)(faceTop ? elementColorsIndex : elementColorsIndex + elementLength - 1) * 4u);
+				secondaryColor = ld_color(arena, worldColumnColorsOff + (uint32_t)(faceTop ? elementColorsIndex : elementColorsIndex + elementLength - 1) * 4u);
 			}
 
 			// side of the run, :484-542
@@ -710,7 +725,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 									float wuy = m_lerp(uvAy, uvBy, l);
 									float u = wuy / wux;
 									int colorIdx = m_clampi(f2i_floor(u), 0, elementLength - 1) + elementColorsIndex;
-									st_pixel(tileOut, laneByteOff, y, ld1(arena, worldColumnColorsOff + (uint32_t)colorIdx * 4u));
+									st_pixel_loop(tileOut, laneByteOff, y, ld_color(arena, worldColumnColorsOff + (uint32_t)colorIdx * 4u));
 									if (COUNT) { cnt.C++; cnt.P++; }
 								} while (todo != 0u);
 							}
@@ -775,7 +790,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 								CVX_COUNT(7);
 								const int y = (w << 5) + (__ffs((int)todo) - 1);
 								todo &= todo - 1u;
-								st_pixel(tileOut, laneByteOff, y, secondaryColor);
+								st_pixel_loop(tileOut, laneByteOff, y, secondaryColor);
 								if (COUNT) { cnt.P++; }
 							} while (todo != 0u);
 						}
@@ -810,6 +825,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 
 	while (true) {
 		CVX_BEGIN();
+		CVX_WAITPROBE(9);
 		CVX_COUNT(1);
 		if (--guardSteps <= 0) {
 			return;

@@ -11,7 +11,8 @@ os.environ.setdefault("CVX_GPU_LIB", os.path.join(ROOT, "cpuvox_amd", "libcpuvox
 from cpuvox_amd import gpu, host  # noqa: E402
 
 NAMES = ["(unused)", "look-ahead + cull", "frustum clip", "element walk", "side setup", "side pixels",
-         "top/bottom setup", "top/bottom pixels", "skybox pass"]
+         "top/bottom setup", "top/bottom pixels", "skybox pass", "memory wait at the loop top", "memory wait before the walk",
+         "-", "-", "-", "-", "(stamp bookkeeping)"]
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, default=64)
@@ -32,9 +33,9 @@ ctx.draw_segments_batch(frames, 0)
 ctx.debug_section_cycles(reset=True)
 ctx.draw_segments_batch(frames, 0)
 cyc = ctx.debug_section_cycles()
-total = sum(cyc[:9])
+total = sum(cyc[:16])
 print(f"kernel {ctx.last_draw_ms():.2f} ms for {args.frames} frames (instrumented build; read the shares, not the time)")
 for i, (n, c) in enumerate(zip(NAMES, cyc)):
     lanes = 64.0 * cyc[16 + i] / max(1, c)
     print(f"{n:28s} {c:16d} {100.0 * c / total:6.2f} %   mean active lanes {lanes:5.1f}")
-print(f"overall mean active lanes {64.0 * sum(cyc[16:25]) / total:5.1f} of 64")
+

@@ -55,6 +55,13 @@
 	           "v_mad_u32_u24 %4, %8, %9, %4\n v_mad_u32_u24 %5, %8, %9, %5\n v_mad_u32_u24 %6, %8, %9, %6\n v_mad_u32_u24 %7, %8, %9, %7\n")             \
 	X(ffbl, "v_ffbl_b32 %0, %0\n v_ffbl_b32 %1, %1\n v_ffbl_b32 %2, %2\n v_ffbl_b32 %3, %3\n v_ffbl_b32 %4, %4\n v_ffbl_b32 %5, %5\n v_ffbl_b32 %6, %6\n v_ffbl_b32 %7, %7\n") \
 	X(mov, "v_mov_b32 %0, %8\n v_mov_b32 %1, %8\n v_mov_b32 %2, %8\n v_mov_b32 %3, %8\n v_mov_b32 %4, %8\n v_mov_b32 %5, %8\n v_mov_b32 %6, %8\n v_mov_b32 %7, %8\n") \
+	X(salu_and, "s_and_b64 s[20:21], s[20:21], s[22:23]\n s_or_b64 s[22:23], s[22:23], s[24:25]\n s_and_b64 s[24:25], s[24:25], s[26:27]\n s_or_b64 s[26:27], s[26:27], s[20:21]\n"        \
+	            "s_and_b64 s[20:21], s[20:21], s[22:23]\n s_or_b64 s[22:23], s[22:23], s[24:25]\n s_and_b64 s[24:25], s[24:25], s[26:27]\n s_or_b64 s[26:27], s[26:27], s[20:21]\n")       \
+	X(salu_valu_mix, "s_and_b64 s[20:21], s[20:21], s[22:23]\n v_add_f32 %0, %8, %0\n s_or_b64 s[22:23], s[22:23], s[24:25]\n v_add_f32 %1, %8, %1\n"                                  \
+	                 "s_and_b64 s[24:25], s[24:25], s[26:27]\n v_add_f32 %2, %8, %2\n s_or_b64 s[26:27], s[26:27], s[20:21]\n v_add_f32 %3, %8, %3\n")                                 \
+	X(cmp_saveexec, "v_cmp_lt_f32 vcc, %8, %0\n s_and_saveexec_b64 s[20:21], vcc\n v_add_f32 %0, %8, %0\n s_or_b64 exec, exec, s[20:21]\n"                                              \
+	                "v_cmp_lt_f32 vcc, %8, %1\n s_and_saveexec_b64 s[20:21], vcc\n v_add_f32 %1, %8, %1\n s_or_b64 exec, exec, s[20:21]\n")                                             \
+	X(snop, "s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n")                                                                                   \
 	X(lshl_add_u64, "v_lshl_add_u64 %10, %12, 3, %10\n v_lshl_add_u64 %11, %12, 3, %11\n v_lshl_add_u64 %13, %12, 3, %13\n v_lshl_add_u64 %14, %12, 3, %14\n" \
 	                "v_lshl_add_u64 %10, %12, 3, %10\n v_lshl_add_u64 %11, %12, 3, %11\n v_lshl_add_u64 %13, %12, 3, %13\n v_lshl_add_u64 %14, %12, 3, %14\n")
 
