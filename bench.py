@@ -52,6 +52,8 @@ def parse_args():
     ap.add_argument("--pose-range", default=None, help="diagnostics: lo:hi -- only benchmark-path samples lo <= i < hi (e.g. 0:450 = one top/bottom segment per frame)")
     ap.add_argument("--no-exchange", action="store_true", help="N > 1: skip the RCCL tile exchange (replica-style throughput)")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: finish each step's exchange before the next render")
+    ap.add_argument("--torch-exchange", action="store_true", help="N > 1: exchange with torch.distributed P2P ops instead of cvx_exchange (the C-ABI path)")
+    ap.add_argument("--latency-frames", type=int, default=200, help="N = 1: frames of the single-frame latency legs (0 = skip)")
     ap.add_argument("--pmc-csv", default=None, help="counter summary of a rocprofv3 --pmc run of THIS command (tools/pmc_passes.sh + "
                     "tools/pmc_aggregate.py): fills roofline.traffic from FETCH_SIZE + WRITE_SIZE; without it traffic is null")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' = single-GPU rehearsal of the N > 1 path "
@@ -60,7 +62,10 @@ def parse_args():
 
 
 def load_world(name: str, rank: int, world_size: int, barrier):
-    """Procedural worlds are built once (rank 0) and shared through a cache file in /tmp."""
+    """Procedural worlds are built once (rank 0) and shared with the other ranks through a cache file in a private
+    directory; the file name carries a hash of the generator's source, and dims / LOD count are checked after loading."""
+    import hashlib
+
     from cpuvox_amd import host
 
     if name.startswith("mill"):
@@ -69,15 +74,24 @@ def load_world(name: str, rank: int, world_size: int, barrier):
 
         return scenes.load_world(name)
     dim = int(name[4:])
-    cache = f"/tmp/cpuvox_{name}_5EED2048.world"
     if world_size == 1:
         return host.WorldSet.procedural(dim, dim, dim, 0x5EED2048)
+    with open(os.path.join(ROOT, "cpuvox_amd", "csrc", "host", "cvx_world.cpp"), "rb") as fh:
+        tag = hashlib.sha256(fh.read()).hexdigest()[:12]
+    cache_dir = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"cpuvox_bench_{os.getuid()}")
+    os.makedirs(cache_dir, mode=0o700, exist_ok=True)
+    if os.stat(cache_dir).st_uid != os.getuid():
+        raise SystemExit(f"{cache_dir} is not mine")
+    cache = os.path.join(cache_dir, f"{name}_5EED2048_{tag}.world")
     if rank == 0 and not os.path.exists(cache):
         ws = host.WorldSet.procedural(dim, dim, dim, 0x5EED2048)
-        ws.save(cache + ".tmp")
-        os.replace(cache + ".tmp", cache)
+        ws.save(cache + f".tmp{os.getpid()}")
+        os.replace(cache + f".tmp{os.getpid()}", cache)
     barrier()
-    return host.WorldSet.load(cache)
+    ws = host.WorldSet.load(cache)
+    if tuple(ws.dims) != (dim, dim, dim) or ws.lod_count != host.LOD_LEVELS:
+        raise SystemExit(f"{cache}: unexpected world {tuple(ws.dims)} with {ws.lod_count} LODs")
+    return ws
 
 
 def main():
@@ -144,10 +158,44 @@ def main():
     plans = tile_outs = None
     send = disp = None
     s_render = s_exchange = None
+    native_plans = None
+    comm = None
+    exchange_path = None
+    ranks_seen = [0]
     if sharded:
         from cpuvox_amd import dist as cdist
 
+        # census: which ranks / devices take part (the first multi-GPU run checks itself)
+        me = {"rank": rank, "device": local_rank, "gpu": torch.cuda.get_device_name(local_rank), "host": os.uname().nodename}
+        census = [None] * N
+        dist.all_gather_object(census, me)
+        ranks_seen = sorted(c["rank"] for c in census)
         plans = [cdist.ShardPlan(frames, W, H, rank, N) for frames in steps_frames]
+        # The exchange behind the C ABI (cvx_shard_plan_* + cvx_exchange on a communicator the library owns); the plans above
+        # stay for verification (assemble) and as the torch.distributed fallback.
+        if args.backend == "nccl" and not args.torch_exchange:
+            try:
+                native_plans = [gpu.NativeShardPlan(pk, W, H, rank, N) for pk in packed]
+                for a, b in zip(native_plans, plans):
+                    assert a.tile_count == b.tile_count and list(a.send_start) == list(b.send_start) and list(a.disp_start) == list(b.disp_start)
+                uid = [gpu.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(uid, src=0)
+                comm = gpu.comm_create(ctx, uid[0], rank, N)
+                exchange_path = "cvx_exchange (grouped ncclSend/ncclRecv inside libcpuvox_gpu, library-owned communicator)"
+            except Exception as e:  # noqa: BLE001
+                native_plans, comm = None, None
+                exchange_path = f"torch.distributed batch_isend_irecv (C-ABI exchange unavailable: {e})"
+            # every rank must take the same path
+            flag = torch.tensor([1 if comm else 0], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if not bool(flag.item()):
+                if comm:
+                    gpu.comm_destroy(comm)
+                native_plans, comm = None, None
+                if exchange_path.startswith("cvx_exchange"):
+                    exchange_path = "torch.distributed batch_isend_irecv (a peer could not create the C-ABI communicator)"
+        else:
+            exchange_path = "torch.distributed batch_isend_irecv"
         send_rows = max(1, max(p.send_total for p in plans))
         disp_rows = max(1, max(p.disp_total for p in plans))
         # two parities: step s+1 renders into the other pair while step s is still on the wire
@@ -165,12 +213,13 @@ def main():
 
     # ---- algorithmic bytes per launch: instrumented pass, outside the timed region -------------------
     ctx.enable_counters(True)
-    alg_bytes, visits, lod_visits = [], [], []
+    alg_bytes, visits, lod_visits, pixels = [], [], [], []
     for s in range(total_steps):
         draw(s, gpu.DRAW_SYNC)
         c = ctx.counters()
         alg_bytes.append(c.algorithmic_bytes())
         visits.append(c.S)
+        pixels.append(c.P)
         lod_visits.append(list(c.lodVisits))
     ctx.enable_counters(False)
 
@@ -189,8 +238,11 @@ def main():
             ev_render.record(s_render)
             s_exchange.wait_event(ev_render)
             with torch.cuda.stream(s_exchange):
-                for req in plans[s].exchange(send[par], disp[par]):
-                    req.wait()
+                if comm:
+                    native_plans[s].exchange(ctx, comm, s_exchange.cuda_stream, send[par].data_ptr(), disp[par].data_ptr())
+                else:
+                    for req in plans[s].exchange(send[par], disp[par]):
+                        req.wait()
                 ev_done[s] = torch.cuda.Event()
                 ev_done[s].record(s_exchange)
             if not overlap:
@@ -237,8 +289,16 @@ def main():
     exchange_verified = None
     if sharded and not args.no_exchange:
         exchange_verified = verify_exchange(total_steps - 1)
+        if not exchange_verified and comm:
+            # never report a number from a run whose frames are wrong: first fall back to the torch.distributed exchange
+            gpu.comm_destroy(comm)
+            comm = None
+            exchange_path = "torch.distributed batch_isend_irecv (cvx_exchange produced wrong frames: reported as a failure of that path)"
+            elapsed = timed(overlap)
+            k_ms_total, k_draws = ctx.draw_time_stats(reset=True)
+            exchange_verified = verify_exchange(total_steps - 1)
         if not exchange_verified and overlap:
-            # never report a number from a run whose frames are wrong: redo the region without overlap
+            # ... then redo the region without overlap
             overlap = False
             elapsed = timed(False)
             k_ms_total, k_draws = ctx.draw_time_stats(reset=True)
@@ -285,7 +345,9 @@ def main():
             "frames_per_step": G,
             "rays_per_frame_mean": round(total_rays / total_frames, 1),
             "parallelism": parallelism,
+            "ranks_seen": ranks_seen,
             "exchange_verified": exchange_verified,
+            "exchange_path": exchange_path,
             "exchange_bytes_per_step_per_gpu": int(np.mean([p.send_total for p in plans]) * 256) if sharded else 0,
             "world_dims": list(dims),
             "lod_distances": lods,
@@ -306,22 +368,38 @@ def main():
         },
     }
 
-    committed_pmc = os.path.join(ROOT, "profiles", "r01_pmc_render_kernel.csv")
-    if not args.pmc_csv and N == 1 and (W, H, F, args.world, args.lod_error) == (1920, 1080, 512, "proc2048", 1.0) and os.path.exists(committed_pmc):
-        args.pmc_csv = committed_pmc  # the counter passes of exactly this command and kernel, collected with tools/pmc_passes.sh
     if args.pmc_csv:
-        # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB per dispatch (fabric requests of the L2, MI355X_MICROARCH.md "HBM"); raw sum:
-        # the guide's x2 correction holds for wide coalesced streams, this kernel's scattered 16/32-byte loads are uncalibrated.
+        # Counter summary of a rocprofv3 --pmc run of THIS command and build (tools/pmc_passes.sh + tools/pmc_aggregate.py); never a
+        # committed file of another build.  rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB per dispatch (fabric requests of the L2,
+        # MI355X_MICROARCH.md "HBM").  The guide's gfx950 rule: FETCH_SIZE counts a wide coalesced read at half its bytes (x2); this
+        # kernel's loads are scattered 16-byte accesses, uncalibrated -- both readings are given, `traffic` is the raw sum.
         import csv
 
         try:
             with open(args.pmc_csv, newline="") as fh:
                 counters = {row["counter"]: float(row["mean_per_launch"]) for row in csv.DictReader(fh)}
-            result["roofline"]["traffic"] = int((counters["FETCH_SIZE"] + counters["WRITE_SIZE"]) * 1024)
-            result["roofline"]["traffic_source"] = (f"{os.path.relpath(args.pmc_csv, ROOT)}: rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE per launch of this command "
-                                                    "(separate counter passes, not this process), raw (uncorrected)")
+            fetch, write = counters["FETCH_SIZE"] * 1024, counters["WRITE_SIZE"] * 1024
+            launches = max(1, k_draws)
+            pixel_bytes = 4 * sum(pixels[s] for s in steps) / launches
+            result["roofline"]["traffic"] = int(fetch + write)
+            result["roofline"]["traffic_detail"] = {
+                "fetch_bytes_raw": int(fetch), "fetch_bytes_x2": int(2 * fetch), "write_bytes": int(write),
+                "algorithmic_pixel_bytes": int(pixel_bytes), "write_amplification": round(write / max(1.0, pixel_bytes), 3),
+                "tcc_hit_rate": (round(counters["TCC_HIT_sum"] / max(1.0, counters["TCC_HIT_sum"] + counters["TCC_MISS_sum"]), 4)
+                                 if "TCC_HIT_sum" in counters and "TCC_MISS_sum" in counters else None),
+                "source": f"{os.path.relpath(args.pmc_csv, ROOT)}: rocprofv3 --pmc passes of this command, per launch of render_kernel<false>",
+            }
         except (OSError, KeyError, ValueError) as e:
-            result["roofline"]["traffic_source"] = f"unreadable counter summary {args.pmc_csv}: {e}"
+            result["roofline"]["traffic_detail"] = {"error": f"unreadable counter summary {args.pmc_csv}: {e}"}
+
+    parity_frames = []
+    if N == 1:
+        # what the GPU rendered for two frames of the LAST timed step (compared with the CPU oracle in the cpu_baseline leg below)
+        last = steps_frames[total_steps - 1]
+        for b in sorted({0, F // 2}):
+            rc = [max(0, sg.RayCount) for sg in last[b].segments]
+            parity_frames.append((b, last[b], ctx.read_raybuffer(b, gpu.RAYBUFFER_TOPDOWN, 0, rc[0] + rc[1]),
+                                  ctx.read_raybuffer(b, gpu.RAYBUFFER_LEFTRIGHT, 0, rc[2] + rc[3])))
 
     if N == 1:
         # Phase 2 (RenderManager.BlitSegments) over the frames of the last step, image left in HBM: reported beside
@@ -341,23 +419,76 @@ def main():
         except Exception as e:  # noqa: BLE001
             result["phase2"] = {"error": str(e)}
 
+    if N == 1 and args.latency_frames > 0:
+        # The reference's own call pattern: ONE blocking DrawSegments per frame (RenderManager.cs:155-167,363), and the same with its two
+        # raybuffer pairs (BUFFER_COUNT = 2, RenderManager.cs:14,53-56) used as a 2-deep pipeline: frame k is submitted (CVX_DRAW_ASYNC)
+        # while the host still holds frame k - 1.  Reported beside the batch metric, never as `value`.
+        try:
+            K = args.latency_frames
+            singles = [frame_for(i) for i in range(K)]
+            packed1 = [ctx.pack_batch([f]) for f in singles]
+            rays1 = sum(f.totalRays for f in singles)
+            for k in range(min(K, 8)):
+                ctx.draw_packed(packed1[k], k % 2, gpu.DRAW_SYNC)
+            ctx.draw_time_stats(reset=True)
+            t0 = time.perf_counter()
+            for k in range(K):
+                ctx.draw_packed(packed1[k], k % 2, gpu.DRAW_SYNC)
+            dt = time.perf_counter() - t0
+            k_ms1, n1 = ctx.draw_time_stats(reset=True)
+            st = torch.cuda.Stream(device)
+            ctx.set_stream(st.cuda_stream)
+            events = []
+            t0 = time.perf_counter()
+            for k in range(K):
+                ctx.draw_packed(packed1[k], k % 2, gpu.DRAW_ASYNC)
+                ev = torch.cuda.Event()
+                ev.record(st)
+                events.append(ev)
+                if k >= 1:
+                    events[k - 1].synchronize()  # the host consumes frame k - 1 while frame k renders
+            events[-1].synchronize()
+            dt2 = time.perf_counter() - t0
+            ctx.set_stream(None)
+            result["latency"] = {
+                "frames": 1, "ms": round(dt / K * 1e3, 4), "fps": round(K / dt, 1), "mrays": round(rays1 / dt / 1e6, 3),
+                "kernel_ms": round(k_ms1 / max(1, n1), 4),
+                "pipelined_2deep": {"ms": round(dt2 / K * 1e3, 4), "fps": round(K / dt2, 1), "mrays": round(rays1 / dt2 / 1e6, 3)},
+                "what": f"{K} single-frame cvx_draw_segments calls (first {K} poses of the bench), blocking / 2-deep CVX_DRAW_ASYNC over two raybuffer pairs; wall clock",
+            }
+        except Exception as e:  # noqa: BLE001
+            result["latency"] = {"error": str(e)}
+
+    parity_failed = False
     if rank == 0 and N == 1 and args.cpu_seconds > 0:  # the CPU baseline is reported at N = 1 only
         try:
-            result["cpu_baseline"] = cpu_baseline(ws, steps_frames[args.warmup], W, H, args.cpu_seconds)
+            result["cpu_baseline"], parity = cpu_baseline(ws, steps_frames[args.warmup], W, H, args.cpu_seconds, parity_frames)
+            result["parity_checked"] = parity["ok"]
+            result["parity"] = parity
+            parity_failed = not parity["ok"]
         except Exception as e:  # noqa: BLE001  (the GPU measurement above stands on its own)
             result["cpu_baseline"] = {"value": None, "unit": "Mrays/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+            result["parity_checked"] = False
+    else:
+        result["parity_checked"] = False  # no oracle leg in this run (N > 1 checks the exchange against single-GPU renders instead)
     if rank == 0:
         print(json.dumps(result), flush=True)
     barrier()
+    if comm:
+        gpu.comm_destroy(comm)
     ctx.close()
     if N > 1:
         dist.destroy_process_group()
+    if parity_failed:
+        raise SystemExit("bench.py: the GPU raybuffers of the timed frames differ from the CPU oracle")
 
 
-def cpu_baseline(ws, frames, W, H, budget_s: float):
+def cpu_baseline(ws, frames, W, H, budget_s: float, parity_frames=()):
     """The CPU oracle (oracle/cvx_oracle.c: the same algorithm, OpenMP parallel-for over rays, grain 1 like
     RenderJob) timed on this box's host cores on a bounded sample of the same frames.  kind = "port":
-    the reference itself (C#/Unity/Burst) cannot run here."""
+    the reference itself (C#/Unity/Burst) cannot run here.  The same leg also checks the GPU: `parity_frames` are
+    raybuffers of the last timed step as read back from the device; the oracle renders the same frames and every pixel
+    the frame writes (rows of the used rays x [origMin, origMax] of their segment) must be identical."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oraclelib as O
@@ -377,7 +508,7 @@ def cpu_baseline(ws, frames, W, H, budget_s: float):
         dt = time.perf_counter() - t0
         if dt >= budget_s or n >= 4096:
             break
-    return {
+    baseline = {
         "value": round(rays / dt / 1e6, 4),
         "unit": "Mrays/s",
         "cores": threads,
@@ -385,6 +516,25 @@ def cpu_baseline(ws, frames, W, H, budget_s: float):
         "fps": round(n / dt, 2),
         "sample": f"{n} frames cycling over the first timed step ({rays} rays), {dt:.1f} s wall, OpenMP {threads} threads, wall clock of orc_draw_segments only",
     }
+    from cpuvox_amd import dist as cdist
+
+    parity = {"ok": True, "frames": [], "pixels_compared": 0, "pixels_differing": 0}
+    for b, fr, g_td, g_lr in parity_frames:
+        o_td, o_lr, _ = O.draw_segments(ws, fr, W, H, counters=False)
+        rc = [max(0, sg.RayCount) for sg in fr.segments]
+        ranges = cdist.segment_pixel_ranges(fr.vanishingPointScreenSpace, W, H)
+        row0 = [0, rc[0], 0, rc[2]]
+        for sg in range(4):
+            g, o = (g_td, o_td) if sg < 2 else (g_lr, o_lr)
+            lo, hi = ranges[sg]
+            a = g[row0[sg]: row0[sg] + rc[sg], lo: hi + 1]
+            e = o[row0[sg]: row0[sg] + rc[sg], lo: hi + 1]
+            parity["pixels_compared"] += int(a.size)
+            parity["pixels_differing"] += int((a != e).sum())
+        parity["frames"].append(b)
+    parity["ok"] = parity["pixels_differing"] == 0 and parity["pixels_compared"] > 0
+    parity["what"] = "frames of the last timed step (buffer indices above): device raybuffers vs the CPU oracle, every pixel the frame writes"
+    return baseline, parity
 
 
 if __name__ == "__main__":

@@ -30,6 +30,8 @@ EXPORTS = [
     "cvx_screen_device_ptr", "cvx_last_draw_ms", "cvx_enable_counters", "cvx_get_counters",
     "cvx_get_raybuffer_layout", "cvx_selftest_math", "cvx_version", "cvx_bind_raybuffers", "cvx_draw_time_stats", "cvx_debug_section_cycles", "cvx_debug_occupancy", "cvx_copy_rows", "cvx_draw_segments_placed",
     "cvx_world_downsample", "cvx_world_build_lods", "cvx_free", "cvx_debug_section_histogram",
+    "cvx_shard_plan_create", "cvx_shard_plan_destroy", "cvx_shard_plan_tile_count", "cvx_shard_plan_sections", "cvx_shard_plan_tile_out",
+    "cvx_comm_unique_id", "cvx_comm_create", "cvx_comm_destroy", "cvx_exchange",
 ]
 
 
@@ -101,6 +103,17 @@ def lib() -> C.CDLL:
                                            C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_float)]
         L.cvx_free.argtypes = [C.c_void_p]
         L.cvx_free.restype = None
+        L.cvx_shard_plan_create.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.cvx_shard_plan_destroy.argtypes = [C.c_void_p]
+        L.cvx_shard_plan_destroy.restype = None
+        L.cvx_shard_plan_tile_count.argtypes = [C.c_void_p]
+        L.cvx_shard_plan_tile_count.restype = C.c_int64
+        L.cvx_shard_plan_sections.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cvx_shard_plan_tile_out.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cvx_comm_unique_id.argtypes = [C.c_void_p]
+        L.cvx_comm_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.cvx_comm_destroy.argtypes = [C.c_void_p]
+        L.cvx_exchange.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -328,3 +341,60 @@ class Context:
         out = np.empty_like(a)
         self._check(lib().cvx_selftest_math(self._h, op, a.size, a.ctypes.data, b.ctypes.data, out.ctypes.data))
         return out
+
+
+class NativeShardPlan:
+    """cvx_shard_plan_* (include/cpuvox_gpu.h): the shard plan of one batch of frames as the library computes it -- host
+    arithmetic only, no GPU needed.  `packed` = Context.pack_batch(frames) or (n, segments, cameras, vps)."""
+
+    def __init__(self, packed, width: int, height: int, rank: int, world_size: int):
+        n, segs, _cams, vps = packed
+        self._keep = packed
+        self._h = C.c_void_p()
+        rc = lib().cvx_shard_plan_create(n, C.addressof(segs), C.addressof(vps), width, height, rank, world_size, C.byref(self._h))
+        if rc != 0:
+            raise CvxError(f"cvx_shard_plan_create failed ({rc}): {lib().cvx_last_error(None).decode()}")
+        self.rank, self.N = rank, world_size
+        self.tile_count = int(lib().cvx_shard_plan_tile_count(self._h))
+        self.send_start = np.zeros(world_size + 1, dtype=np.int64)
+        self.disp_start = np.zeros(world_size + 1, dtype=np.int64)
+        lib().cvx_shard_plan_sections(self._h, self.send_start.ctypes.data, self.disp_start.ctypes.data)
+        self.send_total, self.disp_total = int(self.send_start[-1]), int(self.disp_start[-1])
+
+    def tile_out(self, send_ptr: int, disp_ptr: int) -> np.ndarray:
+        out = np.zeros(max(1, self.tile_count), dtype=np.uint64)
+        lib().cvx_shard_plan_tile_out(self._h, C.c_void_p(send_ptr), C.c_void_p(disp_ptr), out.ctypes.data)
+        return out[: self.tile_count]
+
+    def exchange(self, ctx: "Context", comm: int, hip_stream: int | None, send_ptr: int, disp_ptr: int) -> None:
+        """cvx_exchange: grouped ncclSend / ncclRecv of this batch's sections, enqueued on hip_stream."""
+        ctx._check(lib().cvx_exchange(ctx._h, self._h, C.c_void_p(comm), C.c_void_p(hip_stream or 0), C.c_void_p(send_ptr), C.c_void_p(disp_ptr)))
+
+    def close(self) -> None:
+        if self._h:
+            lib().cvx_shard_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def comm_unique_id() -> bytes:
+    buf = C.create_string_buffer(128)
+    rc = lib().cvx_comm_unique_id(buf)
+    if rc != 0:
+        raise CvxError(f"cvx_comm_unique_id failed ({rc}): {lib().cvx_last_error(None).decode()}")
+    return buf.raw
+
+
+def comm_create(ctx: Context, unique_id: bytes, rank: int, world_size: int) -> int:
+    comm = C.c_void_p()
+    ctx._check(lib().cvx_comm_create(ctx._h, unique_id, rank, world_size, C.byref(comm)))
+    return comm.value
+
+
+def comm_destroy(comm: int) -> None:
+    lib().cvx_comm_destroy(C.c_void_p(comm))

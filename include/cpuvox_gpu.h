@@ -149,6 +149,36 @@ int cvx_set_shard(cvx_context *ctx, int shardIndex, int shardCount);
 
 int cvx_synchronize(cvx_context *ctx);
 
+/*
+ * Multi-GPU frames behind the C ABI.  The reference's only synchronisation is `render.Complete()` (RenderManager.cs:358-363);
+ * sharded over N GPUs (one process and one context per GPU) the equivalent is, per batch of frames:
+ *     plan = cvx_shard_plan_create(frames, rank, N)             -- host arithmetic, identical on every rank
+ *     cvx_shard_plan_tile_out(plan, sendBase, dispBase, out)    -- where this rank's tiles are rendered
+ *     cvx_draw_segments_placed(ctx, ..., out, CVX_DRAW_ASYNC)   -- RaySetupJob .. RenderJob for this rank's tiles
+ *     cvx_exchange(ctx, plan, comm, stream, sendBase, dispBase) -- grouped ncclSend / ncclRecv, one pair per peer
+ * Tile t of frame b (canonical order: segment 0..3, tiles of a segment in ray order) is rendered by rank t % N; frame b is
+ * displayed on rank b % N.  Two areas of 256-byte pixel rows (64 pixels of one tile row) per rank:
+ *     send area     my tiles of frames displayed elsewhere, one section per destination rank, (frame, tile) order
+ *     display area  all tiles of the frames I display, one section per rendering rank, (frame, tile) order -- my own section
+ *                   is written by my kernel, the others arrive from the peers and are exactly their send sections for me
+ * Only rows [origMin, origMax] of a tile exist in either area.  sendStart / dispStart: N + 1 section boundaries in rows.
+ */
+typedef struct cvx_shard_plan cvx_shard_plan;
+int cvx_shard_plan_create(int frameCount, const cvx_segment_data *segments, const float *vanishingPoints, int screenWidth, int screenHeight,
+                          int rank, int worldSize, cvx_shard_plan **out);
+void cvx_shard_plan_destroy(cvx_shard_plan *plan);
+int64_t cvx_shard_plan_tile_count(const cvx_shard_plan *plan);
+int cvx_shard_plan_sections(const cvx_shard_plan *plan, int64_t *sendStart, int64_t *dispStart);
+/* tileOut[i] for cvx_draw_segments_placed (0 = another rank renders tile i); sendBase / dispBase: device addresses of the two areas */
+int cvx_shard_plan_tile_out(const cvx_shard_plan *plan, void *sendBase, void *dispBase, uint64_t *tileOut);
+/* RCCL communicator owned by the library (librccl is loaded on first use): rank 0 makes the 128-byte id, the host passes it to
+ * the other ranks over its own channel, every rank calls cvx_comm_create.  A communicator made elsewhere (ncclComm_t) works too. */
+int cvx_comm_unique_id(void *id128);
+int cvx_comm_create(cvx_context *ctx, const void *id128, int rank, int worldSize, void **comm);
+int cvx_comm_destroy(void *comm);
+/* The exchange of one batch on hipStream (NULL = the context's stream): returns after enqueueing; order the consumer with the stream. */
+int cvx_exchange(cvx_context *ctx, const cvx_shard_plan *plan, void *comm, void *hipStream, void *sendBase, void *dispBase);
+
 /* RenderManager.ClearRayBuffer, RenderManager.cs:58-92 (fills with one ARGB32
  * value, bytes A,R,G,B in memory order packed little-endian in `argb`). */
 int cvx_clear_raybuffer(cvx_context *ctx, int bufferIndex, int which, uint32_t argb);

@@ -63,3 +63,52 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp", "Makefile")):
                 text = open(os.path.join(root, f), errors="ignore").read()
                 assert "oraclelib" not in text and "cvx_oracle" not in text and "libcvx_oracle" not in text, os.path.join(root, f)
+
+
+@pytest.mark.parametrize("world_size", [1, 2, 3, 8])
+def test_native_shard_plan_matches_the_python_plan(world_size):
+    """cvx_shard_plan_* (the multi-GPU plan behind the C ABI, no GPU needed) against cpuvox_amd.dist.ShardPlan: same tile
+    count, same section boundaries, same output address for every tile, for every rank."""
+    import ctypes as C
+
+    import numpy as np
+
+    import scenes
+    from cpuvox_amd import dist as cdist
+
+    W, H = 640, 480
+    ws = scenes.load_world("proc256")
+    frames = [scenes.benchmark_frame(ws, W, H, t, 4.0) for t in (0.0, 0.2, 0.45, 0.6, 0.75, 0.8, 0.9, 1.0, 1.1, 0.33, 0.66)]
+    n = len(frames)
+    segs = (host.SegmentData * (4 * n))()
+    cams = (host.CameraData * n)()
+    vps = (C.c_float * (2 * n))()
+    for i, f in enumerate(frames):
+        for s in range(4):
+            segs[4 * i + s] = f.segments[s]
+        cams[i] = f.camera
+        vps[2 * i], vps[2 * i + 1] = f.vanishingPointScreenSpace[0], f.vanishingPointScreenSpace[1]
+    packed = (n, segs, cams, vps)
+    send_base, disp_base = 0x7F0000000000, 0x7E0000000000
+    rendered = np.zeros(0, dtype=np.int64)
+    for rank in range(world_size):
+        ref = cdist.ShardPlan(frames, W, H, rank, world_size)
+        nat = gpu.NativeShardPlan(packed, W, H, rank, world_size)
+        assert nat.tile_count == ref.tile_count
+        assert np.array_equal(nat.send_start, ref.send_start) and np.array_equal(nat.disp_start, ref.disp_start)
+        a, b = nat.tile_out(send_base, disp_base), ref.tile_out(send_base, disp_base)
+        assert np.array_equal(a, b)
+        rendered = np.concatenate([rendered, np.flatnonzero(a)])
+        nat.close()
+    # every tile of the batch is rendered by exactly one rank
+    assert np.array_equal(np.sort(rendered), np.arange(ref.tile_count))
+
+
+def test_exchange_entry_points_fail_cleanly_without_a_device_or_peers():
+    """cvx_exchange / cvx_comm_*: argument errors are reported, nothing is dereferenced (the data path needs >= 2 GPUs)."""
+    L = gpu.lib()
+    assert L.cvx_exchange(None, None, None, None, None, None) == -1      # CVX_ERR_INVALID_ARGUMENT: no context
+    assert L.cvx_comm_create(None, None, 0, 1, None) == -1
+    assert L.cvx_comm_unique_id(None) == -1
+    assert L.cvx_comm_destroy(None) == 0
+    assert L.cvx_shard_plan_tile_count(None) == 0
