@@ -88,7 +88,7 @@ def lib() -> C.CDLL:
     """Load libcpuvox_host.so (built in-tree by cpuvox_amd/csrc/Makefile)."""
     global _lib
     if _lib is None:
-        path = os.path.join(_HERE, "libcpuvox_host.so")
+        path = os.environ.get("CVX_HOST_LIB") or os.path.join(_HERE, "libcpuvox_host.so")  # CVX_HOST_LIB: another build of the same ABI (sanitizer build in tests)
         if not os.path.exists(path):
             raise RuntimeError(f"{path} missing: run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C cpuvox_amd/csrc`")
         L = C.CDLL(path)

@@ -38,6 +38,20 @@ namespace CpuVox.Gpu
 		public fixed long LodVisits[6];
 	}
 
+	[StructLayout(LayoutKind.Sequential, Pack = 4)]
+	public struct RaybufferLayout
+	{
+		public int Width, RayCapacity, TileRays, TileCapacity;
+		public long TileBytes;
+	}
+
+	[StructLayout(LayoutKind.Sequential, Pack = 4)]
+	public struct RowSpan
+	{
+		public long PoolRow, PackedRow;
+		public int Rows, Kind;
+	}
+
 	public sealed class CvxException : Exception
 	{
 		public readonly int Code;
@@ -76,6 +90,23 @@ namespace CpuVox.Gpu
 		[DllImport(Lib)] public static extern int cvx_enable_counters(IntPtr ctx, int enable);
 		[DllImport(Lib)] public static extern int cvx_get_counters(IntPtr ctx, out Counters counters);
 		[DllImport(Lib)] public static extern IntPtr cvx_version();
+		[DllImport(Lib)] public static extern int cvx_draw_segments_placed(IntPtr ctx, int frameCount, SegmentData* segments, CameraData* cameras, int screenWidth, int screenHeight, float* vanishingPoints, long tileCount, ulong* tileOut, int flags);
+		[DllImport(Lib)] public static extern int cvx_get_raybuffer_layout(IntPtr ctx, int which, out RaybufferLayout layout);
+		[DllImport(Lib)] public static extern int cvx_copy_rows(IntPtr ctx, IntPtr hipStream, int toPacked, long spanCount, RowSpan* spansDevice, void* packedDevice);
+		[DllImport(Lib)] public static extern int cvx_selftest_math(IntPtr ctx, int op, int n, float* a, float* b, float* result);
+		[DllImport(Lib)] public static extern int cvx_debug_occupancy(IntPtr ctx, long ldsBytes, out int blocksPerCU);
+		[DllImport(Lib)] public static extern int cvx_debug_section_cycles(IntPtr ctx, ulong* out32, int reset);
+		[DllImport(Lib)] public static extern int cvx_debug_section_histogram(IntPtr ctx, ulong* out128, int reset);
+		// multi-GPU: shard plan (host arithmetic), library-owned RCCL communicator, tile exchange (RenderManager.cs:358-363 sharded)
+		[DllImport(Lib)] public static extern int cvx_shard_plan_create(int frameCount, SegmentData* segments, float* vanishingPoints, int screenWidth, int screenHeight, int rank, int worldSize, out IntPtr plan);
+		[DllImport(Lib)] public static extern void cvx_shard_plan_destroy(IntPtr plan);
+		[DllImport(Lib)] public static extern long cvx_shard_plan_tile_count(IntPtr plan);
+		[DllImport(Lib)] public static extern int cvx_shard_plan_sections(IntPtr plan, long* sendStart, long* dispStart);
+		[DllImport(Lib)] public static extern int cvx_shard_plan_tile_out(IntPtr plan, void* sendBase, void* dispBase, ulong* tileOut);
+		[DllImport(Lib)] public static extern int cvx_comm_unique_id(void* id128);
+		[DllImport(Lib)] public static extern int cvx_comm_create(IntPtr ctx, void* id128, int rank, int worldSize, out IntPtr comm);
+		[DllImport(Lib)] public static extern int cvx_comm_destroy(IntPtr comm);
+		[DllImport(Lib)] public static extern int cvx_exchange(IntPtr ctx, IntPtr plan, IntPtr comm, IntPtr hipStream, void* sendBase, void* dispBase);
 	}
 
 	/// <summary>
@@ -131,6 +162,28 @@ namespace CpuVox.Gpu
 
 		/// <summary>Rows of a raybuffer in the reference's layout (RayBuffer.Native.GetRayColumn, RayBuffer.cs:121-128).</summary>
 		public void ReadRayBuffer(int bufferIndex, int which, int firstRay, int rayCount, void* dst) { Check(Native.cvx_read_raybuffer(ctx, bufferIndex, which, firstRay, rayCount, dst)); }
+
+		/// <summary>One frame sharded over worldSize GPUs (one process and one GpuRenderer per GPU): this rank renders its tiles straight into
+		/// the send / display areas and the exchange completes the frames this rank displays -- the multi-GPU form of
+		/// `render.Complete()` (RenderManager.cs:358-363).  comm: cvx_comm_create (the 128-byte id travels over the host's own channel).</summary>
+		public void DrawSegmentsSharded(int frameCount, SegmentData* segments, CameraData* cameras, float* vanishingPoints, int screenWidth, int screenHeight,
+		                                int rank, int worldSize, IntPtr comm, void* sendArea, void* displayArea)
+		{
+			int rc = Native.cvx_shard_plan_create(frameCount, segments, vanishingPoints, screenWidth, screenHeight, rank, worldSize, out IntPtr plan);
+			if (rc != 0) { throw new CvxException(rc, Marshal.PtrToStringAnsi(Native.cvx_last_error(IntPtr.Zero))); }
+			try {
+				long tiles = Native.cvx_shard_plan_tile_count(plan);
+				ulong[] tileOut = new ulong[Math.Max(1, tiles)];
+				fixed (ulong* p = tileOut) {
+					Check(Native.cvx_shard_plan_tile_out(plan, sendArea, displayArea, p));
+					Check(Native.cvx_draw_segments_placed(ctx, frameCount, segments, cameras, screenWidth, screenHeight, vanishingPoints, tiles, p, 1));
+				}
+				Check(Native.cvx_exchange(ctx, plan, comm, IntPtr.Zero, sendArea, displayArea));
+				Check(Native.cvx_synchronize(ctx));
+			} finally {
+				Native.cvx_shard_plan_destroy(plan);
+			}
+		}
 
 		public void Dispose()
 		{

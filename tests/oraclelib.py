@@ -53,6 +53,8 @@ _lib = None
 
 
 def build(force: bool = False) -> str:
+    if os.environ.get("CVX_ORACLE_LIB"):  # another build of the oracle (the sanitizer build, tests/test_sanitizers.py)
+        return os.environ["CVX_ORACLE_LIB"]
     path = os.path.join(ORACLE_DIR, "libcvx_oracle.so")
     src = os.path.join(ORACLE_DIR, "cvx_oracle.c")
     if force or not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
