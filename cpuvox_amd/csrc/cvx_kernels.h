@@ -716,17 +716,35 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 							if (todo != 0u) {
 								seen[w << sshift] = m | range;
 								frustumDirMaxWorld = CVX_FLOAT_EPSILON;
-								do {
-									CVX_COUNT(5);
-									const int y = (w << 5) + (__ffs((int)todo) - 1);
-									todo &= todo - 1u;
+								// perspective-correct colour of pixel y of the run's side, :524-531
+								auto colourOffset = [&](int y) -> uint32_t {
 									float l = ((float)y - boundsX) / (boundsY - boundsX); // unlerp
 									float wux = m_lerp(uvAx, uvBx, l);
 									float wuy = m_lerp(uvAy, uvBy, l);
 									float u = wuy / wux;
 									int colorIdx = m_clampi(f2i_floor(u), 0, elementLength - 1) + elementColorsIndex;
-									st_pixel_loop(tileOut, laneByteOff, y, ld_color(arena, worldColumnColorsOff + (uint32_t)colorIdx * 4u));
-									if (COUNT) { cnt.C++; cnt.P++; }
+									return worldColumnColorsOff + (uint32_t)colorIdx * 4u;
+								};
+								// Two pixels per trip: both colour loads are in flight before the first store waits for its colour (a load's
+								// latency is what a trip costs, not its arithmetic).  Same pixels, same order of stores per lane.
+								do {
+									CVX_COUNT(5);
+									const int y0 = (w << 5) + (__ffs((int)todo) - 1);
+									todo &= todo - 1u;
+									const uint32_t c0 = ld_color(arena, colourOffset(y0));
+									const bool second = todo != 0u;
+									int y1 = y0;
+									uint32_t c1 = 0u;
+									if (second) {
+										y1 = (w << 5) + (__ffs((int)todo) - 1);
+										todo &= todo - 1u;
+										c1 = ld_color(arena, colourOffset(y1));
+									}
+									st_pixel_loop(tileOut, laneByteOff, y0, c0);
+									if (second) {
+										st_pixel_loop(tileOut, laneByteOff, y1, c1);
+									}
+									if (COUNT) { cnt.C += second ? 2u : 1u; cnt.P += second ? 2u : 1u; }
 								} while (todo != 0u);
 							}
 						}
