@@ -10,7 +10,7 @@ for counters in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY 
                 "SQ_ACTIVE_INST_FLAT SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC SQ_INSTS_BRANCH SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_FLAT SQ_INST_CYCLES_SALU" \
                 "SQ_IFETCH SQ_INSTS_SMEM SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR"; do
   i=$((i+1))
-  timeout 150 rocprofv3 --pmc $counters --output-format csv -d "$OUT/pass$i" -- python3 "$R/bench.py" --cpu-seconds 0 --frames 128 --steps 2 --warmup 1 "$@" > "$OUT/pass$i.log" 2>&1
+  timeout 150 rocprofv3 --pmc $counters --output-format csv -d "$OUT/pass$i" -- python3 "$R/bench.py" --cpu-seconds 0 --latency-frames 0 --frames 128 --steps 2 --warmup 1 "$@" > "$OUT/pass$i.log" 2>&1
   echo "pass$i rc=$?"
 done
 python3 - "$OUT" <<'PY'

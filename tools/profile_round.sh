@@ -1,0 +1,26 @@
+#!/bin/bash
+# Everything profiles/rNN_* is made from, in one go on the GPU box: tools/profile_round.sh <tag, e.g. r02>
+# (kernel trace + stats, PMC passes, SQ stall / instruction counters of the default bench command; results under gpurun_out/<tag>/)
+TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$R/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd /tmp; export TMPDIR=/tmp
+# 1. kernel trace + stats of the default command (no CPU leg: the profiler would only see it as idle time)
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$R/bench.py" --cpu-seconds 0 --latency-frames 0 > "$OUT/trace_bench.json" 2> "$OUT/trace.log"
+find "$OUT/trace" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
+# 2. counter passes (separate runs, --pmc only)
+bash "$R/tools/pmc_passes.sh" "$OUT/pmc" --cpu-seconds 0 --latency-frames 0 --steps 3 --warmup 1 > "$OUT/pmc_passes.log" 2>&1
+python3 "$R/tools/pmc_aggregate.py" "$OUT/pmc" "render_kernel<false>" > "$OUT/pmc_render_kernel.csv"
+# 3. the bench line of this build with the measured traffic attached (and the CPU leg, parity check, latency legs)
+timeout 900 python3 "$R/bench.py" --pmc-csv "$OUT/pmc_render_kernel.csv" > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
+# 4. SQ counters (128 frames per launch)
+bash "$R/tools/pmc_stalls.sh" libcpuvox_gpu.so > "$OUT/sq_counters.txt" 2>&1
+bash "$R/tools/pmc_insts.sh" libcpuvox_gpu.so >> "$OUT/sq_counters.txt" 2>&1
+# 5. other shapes
+timeout 600 python3 "$R/bench.py" --cpu-seconds 0 --latency-frames 0 --frames 128 --steps 4 --warmup 1 --width 3840 --height 2160 > "$OUT/bench_config4_1gpu.json" 2>/dev/null
+timeout 900 python3 "$R/bench.py" --cpu-seconds 0 --latency-frames 0 --frames 64 --steps 4 --warmup 1 --width 3840 --height 2160 --world proc4096 --lod-error 4 > "$OUT/bench_config5_1gpu.json" 2>/dev/null
+rm -rf "$OUT/trace" "$OUT/pmc"/pass*/runc "$OUT"/pmc/pass*/*/*agent_info.csv 2>/dev/null
+ls -la "$OUT"
+cat "$OUT/kernel_stats.csv" | head -8
+cat "$OUT/pmc_render_kernel.csv"
