@@ -92,6 +92,7 @@ struct cvx_context {
 	int maskWordsNeeded = 1;         // LDS mask words per lane of the widest [origMin, origMax] window in the current launch
 	int ldsWordsNeeded = CVX_WAVE;   // LDS words (mask words x lanes) of the largest wave of the current launch
 	int maxWaveMaskWords = 40 * CVX_WAVE; // LDS budget per wave: 10 KB = 16 waves per CU; wider tiles are cut into narrower waves
+	bool maxWaveMaskWordsAuto = true;     // ... chosen per launch by DrawBatch's cost model unless CVX_MAX_WAVE_MASK_WORDS pins it
 
 	int shardIndex = 0, shardCount = 1;
 	bool countersEnabled = false;

@@ -441,7 +441,7 @@ int cvx_create(int device, cvx_context **out)
 		}
 		if (const char *v = std::getenv("CVX_MAX_WAVE_MASK_WORDS")) { // diagnostics: LDS budget per wave in mask words (x 4 bytes)
 			const int w = std::atoi(v);
-			if (w >= 64 && w <= 40960) { ctx->maxWaveMaskWords = w; }
+			if (w >= 64 && w <= 40960) { ctx->maxWaveMaskWords = w; ctx->maxWaveMaskWordsAuto = false; }
 		}
 		if (const char *v = std::getenv("CVX_MIN_MASK_WORDS")) {
 			const int w = std::atoi(v);
@@ -625,6 +625,30 @@ int DrawBatch(cvx_context *ctx, int frameCount, const cvx_segment_data *segments
 		// lanes.  A tile whose window needs more words (a left / right segment spanning most of a 1920-pixel row, any
 		// segment at 4K) is therefore rendered by 2, 4, ... narrower waves, so ONE wide tile no longer takes the
 		// occupancy of the whole launch down.
+		// The budget itself is chosen per launch: a small one keeps 16 waves resident but cuts wide tiles into narrow waves
+		// (which repeat the per-step work of a wave), a large one keeps the tiles whole at fewer resident waves.  Cost model
+		// fitted to the sweeps in profiles/r02_occupancy.md: a wave of 64 / 32 / 16 / 8 ... lanes costs 1 / 0.68 / 0.40 / 0.25 ... of
+		// a full one, and throughput grows with (resident waves)^0.4 (at most 16 per CU: 128 VGPRs).  1080p picks 10 KB (every
+		// top / bottom tile stays whole), 4K picks 17 KB (68-word top / bottom tiles whole, left / right tiles halved).
+		int budget = ctx->maxWaveMaskWords;
+		if (ctx->maxWaveMaskWordsAuto) {
+			static const int candidates[] = { 40 * CVX_WAVE, 48 * CVX_WAVE, 60 * CVX_WAVE, 68 * CVX_WAVE, 80 * CVX_WAVE, 96 * CVX_WAVE, 120 * CVX_WAVE, 160 * CVX_WAVE, 256 * CVX_WAVE, 512 * CVX_WAVE };
+			static const double laneCost[7] = { 1.0, 0.68, 0.40, 0.25, 0.16, 0.11, 0.08 }; // 64, 32, 16, 8, 4, 2, 1 lanes
+			double best = 0.0;
+			for (int candidate : candidates) {
+				const int resident = std::min(16, (int)(163840 / ((size_t)candidate * 4)));
+				if (resident < 1) { continue; }
+				double work = 0.0;
+				for (size_t i = 0; i < n; i++) {
+					int s2 = split, level = 0;
+					while ((1 << level) < s2) { level++; }
+					while (s2 < CVX_WAVE && ctx->hostTileWords[i] * (CVX_WAVE / s2) > candidate) { s2 *= 2; level++; }
+					work += (double)s2 * laneCost[level];
+				}
+				const double cost = work / std::pow((double)resident, 0.4);
+				if (best == 0.0 || cost < best) { best = cost; budget = candidate; }
+			}
+		}
 		std::vector<DevTile> sorted;
 		sorted.reserve(n * (size_t)split);
 		int ldsWords = 1; // words * lanes of the largest wave
@@ -632,7 +656,7 @@ int DrawBatch(cvx_context *ctx, int frameCount, const cvx_segment_data *segments
 			DevTile t = ctx->hostTiles[order[i]];
 			const int words = ctx->hostTileWords[order[i]];
 			int tileSplit = split;
-			while (tileSplit < CVX_WAVE && words * (CVX_WAVE / tileSplit) > ctx->maxWaveMaskWords) { tileSplit *= 2; }
+			while (tileSplit < CVX_WAVE && words * (CVX_WAVE / tileSplit) > budget) { tileSplit *= 2; }
 			const int lanesPerWave = CVX_WAVE / tileSplit;
 			ldsWords = std::max(ldsWords, words * lanesPerWave);
 			if (tileSplit == 1) {
