@@ -848,6 +848,22 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		if (--guardSteps <= 0) {
 			return;
 		}
+#ifdef CVX_EXP_EXTRA_VALU /* sensitivity experiment: N extra vector instructions per column step (results unchanged) */
+		{
+			float pad_ = curDistLast;
+#pragma unroll
+			for (int k_ = 0; k_ < CVX_EXP_EXTRA_VALU; k_++) { asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(pad_)); }
+			asm volatile("" ::"v"(pad_));
+		}
+#endif
+#ifdef CVX_EXP_EXTRA_SALU /* ... N extra scalar instructions per column step */
+		{
+			int spad_ = 0;
+#pragma unroll
+			for (int k_ = 0; k_ < CVX_EXP_EXTRA_SALU; k_++) { asm volatile("s_add_u32 %0, %0, 1" : "+s"(spad_)::"scc"); }
+			asm volatile("" ::"s"(spad_));
+		}
+#endif
 		// ---- look ahead: move the DDA to the next column (Step :613 / :252 / :273, then the LOD check of the
 		// next iteration :237-243) and start fetching its record; nothing below touches `ray` again.
 		curDistLast = ray.distLast;
