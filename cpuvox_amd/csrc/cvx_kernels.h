@@ -856,6 +856,22 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			asm volatile("" ::"v"(pad_));
 		}
 #endif
+#ifdef CVX_EXP_EXTRA_PK /* ... N extra packed-f32 instructions per column step */
+		{
+			double pad2_ = (double)curDistLast;
+#pragma unroll
+			for (int k_ = 0; k_ < CVX_EXP_EXTRA_PK; k_++) { asm volatile("v_pk_add_f32 %0, %0, %0" : "+v"(pad2_)); }
+			asm volatile("" ::"v"(pad2_));
+		}
+#endif
+#ifdef CVX_EXP_EXTRA_SLOW /* ... N extra half-rate vector instructions (v_max_f32) per column step */
+		{
+			float pad3_ = curDistLast;
+#pragma unroll
+			for (int k_ = 0; k_ < CVX_EXP_EXTRA_SLOW; k_++) { asm volatile("v_max_f32 %0, %0, %0" : "+v"(pad3_)); }
+			asm volatile("" ::"v"(pad3_));
+		}
+#endif
 #ifdef CVX_EXP_EXTRA_SALU /* ... N extra scalar instructions per column step */
 		{
 			int spad_ = 0;
