@@ -44,7 +44,11 @@ __device__ __forceinline__ uint2 ld2(gptr_arena arena, uint32_t byteOff) { const
 __device__ __forceinline__ uint32_t ld1(gptr_arena arena, uint32_t byteOff) { return *(const CVX_GLOBAL uint32_t *)(arena + byteOff); }
 // Raybuffer tile: wave-uniform tile base + 32-bit byte offset (pixel row y of the lane's column: y * 256 + lane * 4)
 typedef CVX_GLOBAL uint8_t *gptr_tile;
+#ifdef CVX_EXP_LANE_MAJOR /* traffic experiment only (read-back / blit do not know this layout): a lane's pixels contiguous, laneByteOff = lane * colLen * 4 */
+__device__ __forceinline__ void st_pixel(gptr_tile tile, uint32_t laneByteOff, int y, uint32_t argb) { *(CVX_GLOBAL uint32_t *)(tile + ((uint32_t)y * 4u + laneByteOff)) = argb; }
+#else
 __device__ __forceinline__ void st_pixel(gptr_tile tile, uint32_t laneByteOff, int y, uint32_t argb) { *(CVX_GLOBAL uint32_t *)(tile + ((uint32_t)y * (CVX_WAVE * 4u) + laneByteOff)) = argb; }
+#endif
 #ifdef CVX_EXP_NOSTORE /* timing experiment only (wrong pictures): what the pixel stores of the column loop cost */
 #define st_pixel_loop(tile, lane, y, argb) asm volatile("" ::"v"(argb), "v"(y))
 #else
@@ -500,6 +504,14 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 	int extFirst = 0;                 // their position in the column's list: 0 (top-down walk) or max(0, solidCount - 4) (bottom-up)
 	unsigned int consumed = 0u;       // counting variant: elements the reference's walk has dereferenced in this column
 	float worldBoundsMin, worldBoundsMax;
+#ifdef CVX_PROFILE_COUNTS
+	// carry-over census: lastColumnDrawn = the previous DDA step of this lane ran drawColumn at the same LOD, so its
+	// camSpace*Next are this column's camSpace*Last; lastClipMin / lastClipMax = frustum bounds of a clip the previous step computed
+	bool lastColumnDrawn = false, lastColumnClipped = false;
+	float lastClipMin = 0.0f, lastClipMax = 0.0f;
+	bool thisColumnClipped = false;
+	bool prevDrawnShared = false, prevClippedShared = false; // the two flags as they were when the current column started
+#endif
 
 	// Clip, element walk and pixel writes of ExecuteRay (:289-611) for the current column;
 	// false = the ray is finished (every such exit is WriteSkybox).
@@ -515,8 +527,25 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		const f3 camSpaceMaxNext = f3_madd(planeStartTop, planeDir, curDistNext);
 
 		CVX_COUNT(8);
+#ifdef CVX_PROFILE_COUNTS
+		if (__ballot(!prevDrawnShared) == 0ull) { CVX_COUNT(13); } // every lane entering could take camSpace*Last from the previous column
+		thisColumnClipped = false;
+#endif
 		if (curDistLast > 2.0f && frustumDirMaxWorld == CVX_FLOAT_EPSILON) { // :295-422
 			CVX_COUNT(2);
+#ifdef CVX_PROFILE_COUNTS
+			{
+				const bool hit = prevClippedShared && lastClipMin == frustumBoundsMin && lastClipMax == frustumBoundsMax;
+				const bool hitMax = prevClippedShared && lastClipMax == frustumBoundsMax;
+				if (__ballot(!hit) == 0ull) { CVX_COUNT(14); }    // every clipping lane could reuse the whole Last half
+				if (__ballot(!hitMax) == 0ull) { CVX_COUNT(15); } // ... at least what depends on frustumBoundsMax only
+				if (hit) { prof.lanes[14]++; }
+				if (hitMax) { prof.lanes[15]++; }
+				thisColumnClipped = true;
+				lastClipMin = frustumBoundsMin;
+				lastClipMax = frustumBoundsMax;
+			}
+#endif
 			float clipLastMinLerp, clipLastMaxLerp, clipNextMinLerp, clipNextMaxLerp;
 			// CameraData.cs:103,111.  frustumBounds = (integer pixel in [-1, 16385]) -/+ 0.501: magnitude in [0.499, 16386], always "safe"
 			const float invFrustumMin = quot_safe(1.0f, recip_safe(frustumBoundsMin)), invFrustumMax = quot_safe(1.0f, recip_safe(frustumBoundsMax));
@@ -918,6 +947,14 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 #pragma unroll
 			for (int k = 0; k < 6; k++) { cnt.lod[k] += (curLod == k) ? 1u : 0u; }
 		}
+#ifdef CVX_PROFILE_COUNTS
+		const bool sameLod = curLod == lod; // (the look-ahead has already applied a LOD switch for the next column)
+		const bool prevDrawn = lastColumnDrawn, prevClipped = lastColumnClipped;
+		prevDrawnShared = prevDrawn;
+		prevClippedShared = prevClipped;
+		lastColumnDrawn = false; // an empty or culled column breaks the chain
+		lastColumnClipped = false;
+#endif
 		if ((header.z >> 16) != 0u) { // RunCount > 0: not an empty column (:251-256)
 			bool draw = true;
 			worldBoundsMin = 0.0f;
@@ -946,6 +983,10 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 				if (!goOn) {
 					return;
 				}
+#ifdef CVX_PROFILE_COUNTS
+				lastColumnDrawn = sameLod;
+				lastColumnClipped = sameLod && thisColumnClipped;
+#endif
 			}
 			CVX_BEGIN();
 		}
@@ -992,7 +1033,11 @@ __global__ __launch_bounds__(CVX_WAVE, CVX_WAVES_PER_SIMD) void render_kernel(co
 		}
 	}
 	const gptr_tile tileOut = (gptr_tile)tile.out;
+#ifdef CVX_EXP_LANE_MAJOR
+	const uint32_t laneByteOff = (uint32_t)(firstLane + lane) * (uint32_t)S.colLen * 4u;
+#else
 	const uint32_t laneByteOff = (uint32_t)(firstLane + lane) * 4u;
+#endif
 	uint32_t *seen = lds + lane - (wordBase << sshift);
 	ProfLane prof;
 #ifdef CVX_PROFILE_SECTIONS

@@ -29,7 +29,8 @@ ctx.draw_segments_batch(frames, 0)
 c = ctx.counters()
 cyc = ctx.debug_section_cycles()
 print(f"{frames_n} frames: lane-level S={c.S} E={c.E} C={c.C} P={c.P} R={c.R}")
-for k in (1, 8, 2, 3, 4, 9, 10, 5, 6, 11, 12, 7):
+NAMES.update({13: "drawColumn: ALL lanes could carry camSpace*Last", 14: "clip: ALL lanes could reuse the Last half", 15: "clip: ALL lanes same frustumBoundsMax"})
+for k in (1, 8, 13, 2, 14, 15, 3, 4, 9, 10, 5, 6, 11, 12, 7):
     print(f"{NAMES[k]:40s} {cyc[k]:12d}  per wave-step {cyc[k] / max(1, cyc[1]):6.3f}   active lanes per execution {cyc[16 + k] / max(1, cyc[k]):5.1f}")
 hist = ctx.debug_section_histogram()
 print("active lanes per execution, share of executions in buckets 1-8, 9-16, ..., 57-64:")
