@@ -13,6 +13,7 @@
 #include "cvx_frame.h"
 #include "cvx_mesh.h"
 #include "cvx_render_manager.h"
+#include "cvx_image.h"
 #include "cvx_world.h"
 
 struct cvxh_world_set {
@@ -112,6 +113,25 @@ int cvxh_world_from_blobs(int dimX, int dimY, int dimZ, int count, const void *c
 			set->worlds.emplace_back(dims, i, blobs[i], byteLengths[i]);
 		}
 		*out = set.release();
+	} catch (const std::exception &e) {
+		return Fail(e.what());
+	}
+	return CVX_OK;
+}
+
+int cvxh_image_load(const char *path, int32_t *width, int32_t *height, uint8_t *rgba, int64_t capacityBytes)
+{
+	if (!path || !width || !height) { return Fail("bad argument"); }
+	try {
+		cvx::Image img;
+		std::string why;
+		if (!cvx::LoadImageFile(path, img, &why)) { return Fail(why); }
+		*width = img.width;
+		*height = img.height;
+		if (rgba) {
+			if (capacityBytes < (int64_t)img.rgba.size()) { return Fail("image buffer too small"); }
+			std::memcpy(rgba, img.rgba.data(), img.rgba.size());
+		}
 	} catch (const std::exception &e) {
 		return Fail(e.what());
 	}

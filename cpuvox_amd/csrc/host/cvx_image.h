@@ -1,6 +1,7 @@
 // cvx_image.h -- diffuse-texture loading for OBJ materials (map_Kd, SimpleMesh.cs:186-205).  The reference hands the
-// file to UnityEngine's Texture2D.LoadImage (PNG / JPG); Unity is not available here, so PNG is decoded with zlib and
-// uncompressed TGA and binary PPM are accepted as well.  JPEG is rejected with an error (no decoder in this image).
+// file to UnityEngine's Texture2D.LoadImage (PNG / JPG); Unity is not available here, so PNG is decoded with zlib, JPEG
+// (baseline, extended-sequential and progressive Huffman, grey / YCbCr) by the decoder in cvx_image.cpp, and uncompressed TGA
+// and binary PPM are accepted as well.
 #pragma once
 
 #include <cstdint>

@@ -115,6 +115,7 @@ def lib() -> C.CDLL:
         L.cvxh_setup_frame.argtypes = [C.POINTER(CameraPose), C.c_int, C.c_float, C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.POINTER(Frame)]
         L.cvxh_sample_benchmark_path.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]
         L.cvxh_sample_benchmark_path.restype = None
+        L.cvxh_image_load.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p, C.c_int64]
         _lib = L
     return _lib
 
@@ -276,3 +277,12 @@ def sample_benchmark_path(t: float, world_dims):
 
 
 BENCHMARK_PATH_LENGTH = 1.15  # BenchmarkPath.anim:179
+
+
+def load_image(path: str) -> np.ndarray:
+    """Texture2D.LoadImage + GetPixels32 as ObjModel uses them (SimpleMesh.cs:186-205): uint8[H, W, 4] RGBA, row 0 = BOTTOM row."""
+    w, h = C.c_int32(), C.c_int32()
+    _check(lib().cvxh_image_load(path.encode(), C.byref(w), C.byref(h), None, 0))
+    out = np.empty((h.value, w.value, 4), dtype=np.uint8)
+    _check(lib().cvxh_image_load(path.encode(), C.byref(w), C.byref(h), out.ctypes.data, out.size))
+    return out

@@ -121,6 +121,11 @@ void cvxh_sample_benchmark_path(float t, const float worldDims[3], float outPosi
  * CPU quota (cgroup v2 cpu.max). */
 int cvxh_default_threads(void);
 
+/* Texture2D.LoadImage + GetPixels32 as ObjModel uses them for map_Kd textures (SimpleMesh.cs:186-205): decodes a PNG / JPEG / TGA / PPM
+ * file into width * height RGBA8 pixels, row 0 = BOTTOM row.  Call with rgba = NULL to get the size, then again with a buffer of
+ * capacityBytes >= width * height * 4. */
+int cvxh_image_load(const char *path, int32_t *width, int32_t *height, uint8_t *rgba, int64_t capacityBytes);
+
 const char *cvxh_version(void);
 
 #ifdef __cplusplus

@@ -290,7 +290,7 @@ f 1/1 3/3 4/4
 
 def test_obj_material_textures(tmp_path):
     """mtllib / usemtl / map_Kd (ObjModel.cs:44-49, SimpleMesh.cs:152-218, WordBuilder.cs:78-84): voxel colour = vertex colour * texel,
-    texels that are not fully opaque leave no voxel, PNG / TGA / PPM decode to the same world, JPEG is refused."""
+    texels that are not fully opaque leave no voxel, PNG / TGA / PPM decode to the same world, a broken JPEG is refused."""
     # 3x3 texels, all different; GetDiffusePixel maps uv to floor(uv * (size - 1)), so texel column / row 2 is only hit at uv == 1
     opaque = [[(40 * x + 10, 60 * y + 20, 200 - 30 * x, 255) for x in range(3)] for y in range(3)]  # rows top-down
     palette = {px[:3] for row in opaque for px in row}
@@ -340,3 +340,54 @@ def test_obj_material_textures(tmp_path):
     (tmp_path / "quad.mtl").write_text("newmtl painted\nmap_Kd tex.jpg\n")
     with pytest.raises(RuntimeError, match="JPEG"):
         host.WorldSet.from_obj(str(tmp_path / "quad.obj"), 8, flip=(False, False, False))
+
+
+@pytest.mark.parametrize("mode", ["L", "RGB"])
+@pytest.mark.parametrize("options", [
+    dict(quality=95, subsampling=0),                       # 4:4:4 baseline
+    dict(quality=90, subsampling=2),                       # 4:2:0
+    dict(quality=85, subsampling=1),                       # 4:2:2
+    dict(quality=92, subsampling=0, progressive=True),     # progressive (spectral selection + successive approximation)
+    dict(quality=80, subsampling=2, progressive=True),
+    dict(quality=90, subsampling=2, restart_marker_blocks=3),  # restart intervals (ignored by Pillow builds that lack the option)
+])
+def test_jpeg_textures_decode_like_libjpeg(tmp_path, mode, options):
+    """map_Kd JPEG textures (Texture2D.LoadImage in the reference, SimpleMesh.cs:186-205): the decoder of cvx_image.cpp against
+    Pillow's libjpeg on images Pillow encodes here -- sizes that are not multiples of the MCU, grey and YCbCr, subsampled chroma,
+    progressive scans.  Tolerance: +-3 per channel (IDCT rounding differs between decoders; the chroma upsampling is the same filter)."""
+    Image = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(5)
+    W, H = 83, 61
+    ys, xs = np.mgrid[0:H, 0:W]
+    base = np.stack([128 + 100 * np.sin(xs / 9.0) * np.cos(ys / 7.0), 128 + 90 * np.cos(xs / 5.0 + ys / 11.0), 40 + 2.0 * xs + 0.5 * ys], axis=-1)
+    base = np.clip(base + rng.normal(0, 3, base.shape), 0, 255).astype(np.uint8)
+    src = Image.fromarray(base).convert(mode)
+    path = str(tmp_path / "t.jpg")
+    try:
+        src.save(path, "JPEG", **options)
+    except TypeError:
+        pytest.skip("this Pillow does not know one of the save options")
+    ref = np.asarray(Image.open(path).convert("RGB"), dtype=np.int32)[::-1]  # row 0 = bottom, like the loader
+    got = host.load_image(path)
+    assert got.shape == (H, W, 4) and (got[..., 3] == 255).all()
+    err = np.abs(got[..., :3].astype(np.int32) - ref)
+    assert err.max() <= 3 and err.mean() < 0.6, (err.max(), err.mean())
+
+
+def test_jpeg_texture_on_a_voxelised_quad(tmp_path):
+    """The OBJ path end to end with a JPEG map_Kd: same world as with the PNG of the decoded pixels."""
+    Image = pytest.importorskip("PIL.Image")
+    tex = np.zeros((16, 16, 3), dtype=np.uint8)
+    tex[:8, :8] = (200, 40, 40)
+    tex[:8, 8:] = (40, 200, 40)
+    tex[8:, :8] = (40, 40, 200)
+    tex[8:, 8:] = (220, 220, 60)
+    Image.fromarray(tex).save(str(tmp_path / "tex.jpg"), "JPEG", quality=95, subsampling=0)
+    decoded = host.load_image(str(tmp_path / "tex.jpg"))  # row 0 = bottom
+    (tmp_path / "quad.obj").write_text(QUAD_OBJ)
+    (tmp_path / "quad.mtl").write_text("newmtl painted\nmap_Kd tex.jpg\n")
+    ws_jpg = host.WorldSet.from_obj(str(tmp_path / "quad.obj"), 8, flip=(False, False, False))
+    _write_png(tmp_path / "tex.png", [[tuple(int(v) for v in decoded[15 - y, x]) for x in range(16)] for y in range(16)])
+    (tmp_path / "quad.mtl").write_text("newmtl painted\nmap_Kd tex.png\n")
+    ws_png = host.WorldSet.from_obj(str(tmp_path / "quad.obj"), 8, flip=(False, False, False))
+    assert np.array_equal(ws_jpg.storage(0), ws_png.storage(0)) and ws_jpg.lod0_voxels > 0
