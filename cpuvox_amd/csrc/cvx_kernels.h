@@ -500,8 +500,6 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 	int curScale;                     // voxelScale of the current column
 	uint32_t curElementsOff;          // element pool of the current column's LOD (colours): byte offset in the arena
 	uint32_t curRunsOff;              // run list (solid runs 2..) of the current column's LOD
-	uint4 ext = { 0u, 0u, 0u, 0u };   // the first two entries of the current column's run list the walk will need (columns with more than two solid runs)
-	int extFirst = 0;                 // their position in the column's list: 0 (top-down walk) or max(0, solidCount - 4) (bottom-up)
 	unsigned int consumed = 0u;       // counting variant: elements the reference's walk has dereferenced in this column
 	float worldBoundsMin, worldBoundsMax;
 #ifdef CVX_PROFILE_COUNTS
@@ -622,13 +620,11 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 				// the walk's k-th solid run is run k of the record's top-down list, or run solidCount - 1 - k for the bottom-up walk
 				const int j = DIR > 0 ? solidIndex : solidCount - 1 - solidIndex;
 				uint32_t w0, w1;
-				const int rel = j - 2 - extFirst;
-				if (j < 2 || (rel == 0 || rel == 1)) {
-					const bool odd = j < 2 ? (j & 1) != 0 : rel != 0;
-					const uint4 pair = j < 2 ? queue : ext;
-					w0 = odd ? pair.z : pair.x;
-					w1 = odd ? pair.w : pair.y;
-				} else {
+				if (j < 2) {
+					const bool odd = j != 0;
+					w0 = odd ? queue.z : queue.x;
+					w1 = odd ? queue.w : queue.y;
+				} else { // 3-8 % of the columns have more than two solid runs: fetched when the walk gets there (memory waits are < 1 % of wave time)
 					const uint2 run = ld2(arena, columnRunsOff + (uint32_t)(j - 2) * 8u);
 					w0 = run.x;
 					w1 = run.y;
@@ -917,15 +913,6 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		curElementsOff = L.elementsOff;
 		curRunsOff = L.runsOff;
 		const int curLod = lod;
-		// The first two run-list entries the walk needs (3 % of the columns have more than two solid runs) are requested BEFORE the
-		// look-ahead record: vector memory returns in order, so the element walk can wait for them and leave the look-ahead in flight.
-		if ((header.y & 0xFFFFu) > 2u) {
-			const int solids = (int)(header.y & 0xFFFFu);
-			extFirst = DIR > 0 ? 0 : max(0, solids - 4);
-			const uint32_t at = curRunsOff + (header.w + (uint32_t)extFirst) * 8u;
-			const uint2 e0 = ld2(arena, at), e1 = ld2(arena, at + 8u);
-			ext = uint4{ e0.x, e0.y, e1.x, e1.y };
-		}
 		const bool lastColumn = dda_step(ray, farClip); // true: far clip reached after this column
 		// (the LOD check and the fetch are done for every lane, also one that stops after this column: its state is
 		// dead, and an unconditional, in-bounds load is cheaper than branching around it)

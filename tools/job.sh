@@ -1,2 +1,2 @@
 mkdir -p gpurun_out/r2g
-timeout 2400 python3 tools/soak.py 5000 2>&1 | tee gpurun_out/r2g/parity_soak.txt | tail -8
+bash tools/variants.sh "libcpuvox_gpu_base.so libcpuvox_gpu.so" --frames 512 2>&1 | tee gpurun_out/r2g/variants_noext.txt
