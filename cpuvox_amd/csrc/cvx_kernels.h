@@ -774,8 +774,8 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 							}
 						}
 						CVX_END(5);
-						if (nextFreePixelMin > nextFreePixelMax) {
-							return false;
+						if (COUNT && nextFreePixelMin > nextFreePixelMax) {
+							return false; // (the rendering build tests this once per column, below: nothing can be drawn in between)
 						}
 					}
 				}
@@ -839,14 +839,20 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 						}
 					}
 					CVX_END(7);
-					if (nextFreePixelMin > nextFreePixelMax) {
+					if (COUNT && nextFreePixelMin > nextFreePixelMax) {
 						return false;
 					}
 				}
 			}
 		}
 
-		return true;
+		// :537,606: the ray ends once every pixel of its window has been written.  The reference (and the counting build, whose
+		// element count depends on it) leaves right after the pixel loop that closed the window; the rendering build looks once
+		// per column: with the window closed nothing more can be drawn (every pixel of [origMin, origMax] is marked seen), so the
+		// rest of the column changes no pixel.  It touches no mask word outside the window's either: a run that still passes the
+		// overlap test is clamped to rbMin = nextFreePixelMin > rbMax = nextFreePixelMax, and its word loop runs only if both lie
+		// in the same word -- which then holds pixels of the window; the horizon scans never start beyond [origMin, origMax].
+		return COUNT || nextFreePixelMin <= nextFreePixelMax;
 	};
 
 	// column 0: LOD check (:237-243), bounds test and fetch (World.GetVoxelColumn, World.cs:130-142)
