@@ -550,9 +550,8 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			const bool clippedLast = clip_world_bounds(camSpaceMinLast, camSpaceMaxLast, frustumBoundsMin, frustumBoundsMax, invFrustumMin, invFrustumMax, clipLastMinLerp, clipLastMaxLerp);
 			const bool clippedNext = clip_world_bounds(camSpaceMinNext, camSpaceMaxNext, frustumBoundsMin, frustumBoundsMax, invFrustumMin, invFrustumMax, clipNextMinLerp, clipNextMaxLerp);
 
-			if (clippedLast && clippedNext) {
-				return false;
-			}
+			// (:297-299 leaves here when both ends are outside the window; that exit is taken together with the next one below --
+			// nothing in between has an effect that survives the end of the ray)
 			// :300-390, the three cases (only Next visible / only Last visible / both) folded into selects: each
 			// bound comes from the Last or the Next intersection, chosen exactly as the reference's branches do.
 			const bool minFromLast = !clippedLast && (clippedNext || clipLastMinLerp < clipNextMinLerp);
@@ -581,7 +580,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			const int writableMinPixel = f2i_floor(camSpaceClippedMin);
 			const int writableMaxPixel = f2i(ceilf(camSpaceClippedMax));
 
-			if (writableMaxPixel < nextFreePixelMin || writableMinPixel > nextFreePixelMax) {
+			if ((clippedLast && clippedNext) || writableMaxPixel < nextFreePixelMin || writableMinPixel > nextFreePixelMax) {
 				return false;
 			}
 			if (writableMinPixel > nextFreePixelMin) {
@@ -590,8 +589,8 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			if (writableMaxPixel < nextFreePixelMax) {
 				nextFreePixelMax = scan_down(seen, sshift, writableMaxPixel, omin);
 			}
-			if (nextFreePixelMin > nextFreePixelMax) {
-				return false;
+			if (COUNT && nextFreePixelMin > nextFreePixelMax) {
+				return false; // :419 (the rendering build notices at the end of the column)
 			}
 		}
 
@@ -666,10 +665,8 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			const bool faceTop = portionTop < cameraPosYNormalized;
 			const bool faceBottom = !faceTop && portionBottom > cameraPosYNormalized;
 			const bool faceWanted = faceTop ? !(elementBoundsMax > worldBoundsMax) : (faceBottom && !(elementBoundsMin < worldBoundsMin));
-			uint32_t secondaryColor = 0u;
-			if (faceWanted) {
-				secondaryColor = ld_color(arena, worldColumnColorsOff + (uint32_t)(faceTop ? elementColorsIndex : elementColorsIndex + elementLength - 1) * 4u);
-			}
+			// (unconditional: both addresses are colours of this run, and a branch around one load costs more than the load)
+			const uint32_t secondaryColor = ld_color(arena, worldColumnColorsOff + (uint32_t)(faceTop ? elementColorsIndex : elementColorsIndex + elementLength - 1) * 4u);
 
 			// side of the run, :484-542
 			CVX_COUNT(4);

@@ -1,2 +1,2 @@
 mkdir -p gpurun_out/r2g
-timeout 1500 python3 -m pytest tests -x -q -m gpu 2>&1 | grep -E "passed|failed|Error|error" | tee gpurun_out/r2g/gpu_tests.txt
+bash tools/variants.sh "libcpuvox_gpu_base.so libcpuvox_gpu.so" --frames 512 2>&1 | tee gpurun_out/r2g/variants_clipexit.txt | tail -8
