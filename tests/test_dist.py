@@ -2,7 +2,12 @@
 
 Each rank holds only the tiles it "rendered" (tile t of every frame with t % N == rank; the pixel data comes
 from the oracle, re-laid-out into the device's tile-major format by the test) and after TileExchange.run()
-frame f must be complete, bit for bit, on rank f % N."""
+frame f must be complete, bit for bit, on rank f % N.
+
+This is a test of the sharding plan and of the transport (which rows travel where and land where), not of the renderer:
+no GPU output is involved here -- what the GPU renders into these buffers is pinned to the oracle by the -m gpu tests
+(test_zero_copy_sharding_emulated_on_one_gpu, test_two_rank_exchange_emulated_on_one_gpu), and the plan the library
+itself computes (cvx_shard_plan_*) is checked against this Python plan in tests/test_abi.py."""
 import os
 import socket
 import sys
