@@ -404,7 +404,7 @@ int Launch(cvx_context *ctx, int frameCount, int flags)
 
 extern "C" {
 
-const char *cvx_version(void) { return "cpuvox_gpu 0.1 (gfx950)"; }
+const char *cvx_version(void) { return "cpuvox_gpu 0.2 (gfx950)"; }
 
 const char *cvx_last_error(const cvx_context *ctx) { return ctx ? ctx->error.c_str() : g_createError.c_str(); }
 

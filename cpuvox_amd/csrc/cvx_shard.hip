@@ -160,6 +160,17 @@ int cvx_shard_plan_sections(const cvx_shard_plan *plan, int64_t *sendStart, int6
 	return CVX_OK;
 }
 
+int cvx_shard_plan_transfer(const cvx_shard_plan *plan, int peer, int64_t *sendRow, int64_t *sendRows, int64_t *recvRow, int64_t *recvRows)
+{
+	if (!plan || peer < 0 || peer >= plan->worldSize || !sendRow || !sendRows || !recvRow || !recvRows) { return Fail(nullptr, CVX_ERR_INVALID_ARGUMENT, "bad arguments"); }
+	const bool self = peer == plan->rank; // my own section of the display area is written by my kernel: nothing travels
+	*sendRow = plan->sendStart[(size_t)peer];
+	*sendRows = self ? 0 : plan->sendStart[(size_t)peer + 1] - plan->sendStart[(size_t)peer];
+	*recvRow = plan->dispStart[(size_t)peer];
+	*recvRows = self ? 0 : plan->dispStart[(size_t)peer + 1] - plan->dispStart[(size_t)peer];
+	return CVX_OK;
+}
+
 int cvx_shard_plan_tile_out(const cvx_shard_plan *plan, void *sendBase, void *dispBase, uint64_t *tileOut)
 {
 	if (!plan || !tileOut) { return Fail(nullptr, CVX_ERR_INVALID_ARGUMENT, "bad arguments"); }
@@ -225,11 +236,10 @@ int cvx_exchange(cvx_context *ctx, const cvx_shard_plan *plan, void *comm, void 
 	int rc = r.groupStart();
 	if (rc != 0) { return NcclFail(ctx, r, "ncclGroupStart", rc); }
 	for (int peer = 0; peer < N && rc == 0; peer++) {
-		if (peer == plan->rank) { continue; }
-		const int64_t s0 = plan->sendStart[(size_t)peer], s1 = plan->sendStart[(size_t)peer + 1];
-		const int64_t r0 = plan->dispStart[(size_t)peer], r1 = plan->dispStart[(size_t)peer + 1];
-		if (s1 > s0) { rc = r.send(static_cast<uint8_t *>(sendBase) + (size_t)s0 * rowBytes, (size_t)(s1 - s0) * rowBytes, kNcclInt8, peer, comm, st); }
-		if (rc == 0 && r1 > r0) { rc = r.recv(static_cast<uint8_t *>(dispBase) + (size_t)r0 * rowBytes, (size_t)(r1 - r0) * rowBytes, kNcclInt8, peer, comm, st); }
+		int64_t s0, sn, r0, rn;
+		(void)cvx_shard_plan_transfer(plan, peer, &s0, &sn, &r0, &rn); // (0 rows for peer == rank)
+		if (sn > 0) { rc = r.send(static_cast<uint8_t *>(sendBase) + (size_t)s0 * rowBytes, (size_t)sn * rowBytes, kNcclInt8, peer, comm, st); }
+		if (rc == 0 && rn > 0) { rc = r.recv(static_cast<uint8_t *>(dispBase) + (size_t)r0 * rowBytes, (size_t)rn * rowBytes, kNcclInt8, peer, comm, st); }
 	}
 	const int rcEnd = r.groupEnd();
 	if (rc != 0) { return NcclFail(ctx, r, "ncclSend / ncclRecv", rc); }

@@ -30,7 +30,7 @@ EXPORTS = [
     "cvx_screen_device_ptr", "cvx_last_draw_ms", "cvx_enable_counters", "cvx_get_counters",
     "cvx_get_raybuffer_layout", "cvx_selftest_math", "cvx_version", "cvx_bind_raybuffers", "cvx_draw_time_stats", "cvx_debug_section_cycles", "cvx_debug_occupancy", "cvx_copy_rows", "cvx_draw_segments_placed",
     "cvx_world_downsample", "cvx_world_build_lods", "cvx_free", "cvx_debug_section_histogram",
-    "cvx_shard_plan_create", "cvx_shard_plan_destroy", "cvx_shard_plan_tile_count", "cvx_shard_plan_sections", "cvx_shard_plan_tile_out",
+    "cvx_shard_plan_create", "cvx_shard_plan_destroy", "cvx_shard_plan_tile_count", "cvx_shard_plan_sections", "cvx_shard_plan_tile_out", "cvx_shard_plan_transfer",
     "cvx_comm_unique_id", "cvx_comm_create", "cvx_comm_destroy", "cvx_exchange",
 ]
 
@@ -110,6 +110,7 @@ def lib() -> C.CDLL:
         L.cvx_shard_plan_tile_count.restype = C.c_int64
         L.cvx_shard_plan_sections.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.cvx_shard_plan_tile_out.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cvx_shard_plan_transfer.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.cvx_comm_unique_id.argtypes = [C.c_void_p]
         L.cvx_comm_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.cvx_comm_destroy.argtypes = [C.c_void_p]
@@ -365,6 +366,14 @@ class NativeShardPlan:
         out = np.zeros(max(1, self.tile_count), dtype=np.uint64)
         lib().cvx_shard_plan_tile_out(self._h, C.c_void_p(send_ptr), C.c_void_p(disp_ptr), out.ctypes.data)
         return out[: self.tile_count]
+
+    def transfer(self, peer: int):
+        """(send row, send rows, receive row, receive rows) between this rank and `peer` -- what cvx_exchange moves."""
+        a, b, c, d = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        rc = lib().cvx_shard_plan_transfer(self._h, peer, C.byref(a), C.byref(b), C.byref(c), C.byref(d))
+        if rc != 0:
+            raise CvxError(f"cvx_shard_plan_transfer failed ({rc})")
+        return a.value, b.value, c.value, d.value
 
     def exchange(self, ctx: "Context", comm: int, hip_stream: int | None, send_ptr: int, disp_ptr: int) -> None:
         """cvx_exchange: grouped ncclSend / ncclRecv of this batch's sections, enqueued on hip_stream."""

@@ -102,6 +102,7 @@ namespace CpuVox.Gpu
 		[DllImport(Lib)] public static extern void cvx_shard_plan_destroy(IntPtr plan);
 		[DllImport(Lib)] public static extern long cvx_shard_plan_tile_count(IntPtr plan);
 		[DllImport(Lib)] public static extern int cvx_shard_plan_sections(IntPtr plan, long* sendStart, long* dispStart);
+		[DllImport(Lib)] public static extern int cvx_shard_plan_transfer(IntPtr plan, int peer, out long sendRow, out long sendRows, out long recvRow, out long recvRows);
 		[DllImport(Lib)] public static extern int cvx_shard_plan_tile_out(IntPtr plan, void* sendBase, void* dispBase, ulong* tileOut);
 		[DllImport(Lib)] public static extern int cvx_comm_unique_id(void* id128);
 		[DllImport(Lib)] public static extern int cvx_comm_create(IntPtr ctx, void* id128, int rank, int worldSize, out IntPtr comm);

@@ -169,6 +169,9 @@ int cvx_shard_plan_create(int frameCount, const cvx_segment_data *segments, cons
 void cvx_shard_plan_destroy(cvx_shard_plan *plan);
 int64_t cvx_shard_plan_tile_count(const cvx_shard_plan *plan);
 int cvx_shard_plan_sections(const cvx_shard_plan *plan, int64_t *sendStart, int64_t *dispStart);
+/* What travels between this rank and `peer` (what cvx_exchange sends and receives; a host with its own transport can use it directly):
+ * rows [sendRow, sendRow + sendRows) of the send area go to peer, rows [recvRow, recvRow + recvRows) of the display area come from it. */
+int cvx_shard_plan_transfer(const cvx_shard_plan *plan, int peer, int64_t *sendRow, int64_t *sendRows, int64_t *recvRow, int64_t *recvRows);
 /* tileOut[i] for cvx_draw_segments_placed (0 = another rank renders tile i); sendBase / dispBase: device addresses of the two areas */
 int cvx_shard_plan_tile_out(const cvx_shard_plan *plan, void *sendBase, void *dispBase, uint64_t *tileOut);
 /* RCCL communicator owned by the library (librccl is loaded on first use): rank 0 makes the 128-byte id, the host passes it to

@@ -99,6 +99,17 @@ def test_native_shard_plan_matches_the_python_plan(world_size):
         a, b = nat.tile_out(send_base, disp_base), ref.tile_out(send_base, disp_base)
         assert np.array_equal(a, b)
         rendered = np.concatenate([rendered, np.flatnonzero(a)])
+        # what cvx_exchange sends / receives per peer == the slices the Python exchange hands to isend / irecv, and the two sides of
+        # every pair agree on the size (rank r sends to p exactly what p expects from r)
+        for peer in range(world_size):
+            s0, sn, r0, rn = nat.transfer(peer)
+            if peer == rank:
+                assert (sn, rn) == (0, 0)
+                continue
+            assert (s0, sn) == (int(ref.send_start[peer]), int(ref.send_start[peer + 1] - ref.send_start[peer]))
+            assert (r0, rn) == (int(ref.disp_start[peer]), int(ref.disp_start[peer + 1] - ref.disp_start[peer]))
+            other = cdist.ShardPlan(frames, W, H, peer, world_size)
+            assert sn == int(other.disp_start[rank + 1] - other.disp_start[rank]) and rn == int(other.send_start[rank + 1] - other.send_start[rank])
         nat.close()
     # every tile of the batch is rendered by exactly one rank
     assert np.array_equal(np.sort(rendered), np.arange(ref.tile_count))
