@@ -178,8 +178,15 @@ def main():
                 native_plans = [gpu.NativeShardPlan(pk, W, H, rank, N) for pk in packed]
                 for a, b in zip(native_plans, plans):
                     assert a.tile_count == b.tile_count and list(a.send_start) == list(b.send_start) and list(a.disp_start) == list(b.disp_start)
-                uid = [gpu.comm_unique_id() if rank == 0 else None]
+                uid = [None]
+                if rank == 0:
+                    try:
+                        uid[0] = gpu.comm_unique_id()
+                    except Exception as e:  # noqa: BLE001  (the broadcast below must still happen: the peers are waiting in it)
+                        uid[0] = f"error: {e}"
                 dist.broadcast_object_list(uid, src=0)
+                if not isinstance(uid[0], bytes):
+                    raise RuntimeError(f"rank 0 could not make a RCCL id ({uid[0]})")
                 comm = gpu.comm_create(ctx, uid[0], rank, N)
                 exchange_path = "cvx_exchange (grouped ncclSend/ncclRecv inside libcpuvox_gpu, library-owned communicator)"
             except Exception as e:  # noqa: BLE001
