@@ -135,6 +135,8 @@ float EstimateTileCost(const cvx_context *ctx, const DevFrame &F, const DevSegme
 		if (tb < t1) { t1 = tb; }
 	}
 	if (t1 <= t0) { return 0.f; }
+	// (weighting the far part by its LOD -- a step at LOD l crosses 2^l voxels -- was measured and orders the launch slightly
+	// worse: 33.3 vs 33.05 ms; with this order the wave slots stay ~100 % occupied to the end of the launch, random order costs 19 %)
 	return (t1 - t0) * (std::fabs(dx) + std::fabs(dz));
 }
 
@@ -612,6 +614,19 @@ int DrawBatch(cvx_context *ctx, int frameCount, const cvx_segment_data *segments
 		}
 		const std::vector<float> &cost = ctx->hostTileCost;
 		std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+		if (const char *v = std::getenv("CVX_TILE_ORDER")) { // diagnostics: how much the launch order matters
+			if (!std::strcmp(v, "reverse")) {
+				std::reverse(order.begin(), order.end());
+			} else if (!std::strcmp(v, "frame")) {
+				for (size_t i = 0; i < n; i++) { order[i] = (uint32_t)i; }
+			} else if (!std::strcmp(v, "random")) {
+				uint32_t state = 12345u;
+				for (size_t i = n; i > 1; i--) {
+					state = state * 1664525u + 1013904223u;
+					std::swap(order[i - 1], order[(size_t)(state >> 8) % i]);
+				}
+			}
+		}
 		// Small batches (a single interactive frame is ~60 tiles on a chip with 1024 SIMDs): every tile is cut into 2, 4, ...
 		// 64 sub-tiles of consecutive rays, one wave each.  A wave's cost per column step is the union of what its rays
 		// need, so narrower waves finish sooner; with few waves there are idle SIMDs to run them on (1 frame: 6.7 -> 4.0 ms at
