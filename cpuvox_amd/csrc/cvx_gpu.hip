@@ -390,6 +390,8 @@ int Launch(cvx_context *ctx, int frameCount, int flags)
 		dim3 grid((unsigned)nTiles), block(CVX_WAVE);
 		if (ctx->countersEnabled) {
 			hipLaunchKernelGGL((cvxk::render_kernel<true>), grid, block, ldsBytes, ctx->stream, ctx->devFrames, ctx->devTiles, ctx->devWorld, ctx->devCounters);
+		} else if (ctx->renderStateMachine) {
+			hipLaunchKernelGGL(cvxk::render_sm_kernel, grid, block, ldsBytes, ctx->stream, ctx->devFrames, ctx->devTiles, ctx->devWorld, cvxk::SmParams{ ctx->smThreshold });
 		} else {
 			hipLaunchKernelGGL((cvxk::render_kernel<false>), grid, block, ldsBytes, ctx->stream, ctx->devFrames, ctx->devTiles, ctx->devWorld, ctx->devCounters);
 		}
@@ -444,6 +446,11 @@ int cvx_create(int device, cvx_context **out)
 		if (const char *v = std::getenv("CVX_MAX_WAVE_MASK_WORDS")) { // diagnostics: LDS budget per wave in mask words (x 4 bytes)
 			const int w = std::atoi(v);
 			if (w >= 64 && w <= 40960) { ctx->maxWaveMaskWords = w; ctx->maxWaveMaskWordsAuto = false; }
+		}
+		if (const char *v = std::getenv("CVX_RENDER_SM")) { ctx->renderStateMachine = std::atoi(v) != 0; }
+		if (const char *v = std::getenv("CVX_SM_THRESHOLD")) {
+			const int t = std::atoi(v);
+			if (t >= 1 && t <= 64) { ctx->smThreshold = t; }
 		}
 		if (const char *v = std::getenv("CVX_MIN_MASK_WORDS")) {
 			const int w = std::atoi(v);
@@ -912,7 +919,7 @@ int cvx_debug_section_cycles(cvx_context *ctx, uint64_t out[32], int reset)
 {
 	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
 	if (!out) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "out is NULL"); }
-#ifdef CVX_PROFILE_SECTIONS
+#if defined(CVX_PROFILE_SECTIONS) || defined(CVX_SM_STATS)
 	CVX_HIP(ctx, hipSetDevice(ctx->device));
 	CVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	unsigned long long tmp[32];

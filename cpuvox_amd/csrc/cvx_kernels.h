@@ -1103,6 +1103,10 @@ __global__ __launch_bounds__(CVX_WAVE, CVX_WAVES_PER_SIMD) void render_kernel(co
 	}
 }
 
+} // namespace cvxk
+#include "cvx_render_sm.h"
+namespace cvxk {
+
 // ---------------------------------------------------------------------------
 // untile: tile-major pool -> the reference's ray-major rows (RayBuffer.cs:121-128)
 // rows [firstRay, firstRay+rayCount) of buffer `which`; count0 = RayCount of the

@@ -222,6 +222,30 @@ def test_sub_tile_split_is_invisible(split, monkeypatch):
         ctx.close()
 
 
+@pytest.mark.parametrize("threshold", [0, 1, 64])
+def test_state_machine_kernel_is_bit_exact(threshold, monkeypatch):
+    """CVX_RENDER_SM=1 selects render_sm_kernel (cvx_render_sm.h): the same per-ray arithmetic, but the wave schedules the blocks of
+    ExecuteRay per lane instead of walking all rays column by column.  An experiment (slower, profiles/r02_experiments.md) kept
+    behind the switch; its pixels must not depend on the schedule: default thresholds, every non-empty block per pass (1),
+    fullest block only (64)."""
+    monkeypatch.setenv("CVX_RENDER_SM", "1")
+    if threshold:
+        monkeypatch.setenv("CVX_SM_THRESHOLD", str(threshold))
+    ctx = gpu.Context(0)
+    try:
+        for name in ("mill256_t0", "mill512_t075_1080p", "proc256_t04_lod8", "proc256_t075_lod8"):
+            if name not in scenes.SCENES:
+                continue
+            ws, fr, W, H = scenes.scene_frame(name)
+            ctx.upload_world(ws)
+            ctx.set_resolution(W, H)
+            g_td, g_lr = _render_gpu(ctx, fr)
+            o_td, o_lr, _ = O.draw_segments(ws, fr, W, H, clear=CLEAR)
+            _compare(f"{name} state machine T={threshold}", fr, g_td, g_lr, o_td, o_lr)
+    finally:
+        ctx.close()
+
+
 def test_cpp_example_on_the_c_abis(tmp_path):
     """examples/flythrough.cpp: world building, camera, the RenderManager twin and the GPU library used from plain C++ through
     the two C ABIs (no Python in the loop); the image it writes for path key t = 0 equals the Python-driven render of the same pose."""
