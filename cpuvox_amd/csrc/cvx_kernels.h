@@ -740,6 +740,9 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 								frustumDirMaxWorld = CVX_FLOAT_EPSILON;
 								// perspective-correct colour of pixel y of the run's side, :524-531
 								auto colourOffset = [&](int y) -> uint32_t {
+#ifdef CVX_EXP_NOTEX /* timing experiment only (wrong pictures): what the per-pixel texture arithmetic costs */
+									return worldColumnColorsOff + (uint32_t)(elementColorsIndex + (y & 0)) * 4u;
+#endif
 									float l = ((float)y - boundsX) / (boundsY - boundsX); // unlerp
 									float wux = m_lerp(uvAx, uvBx, l);
 									float wuy = m_lerp(uvAy, uvBy, l);
