@@ -421,8 +421,21 @@ def main():
             ctx.synchronize()
             blit_ms = (time.perf_counter() - t0) * 1e3 / F
             phase1_ms = elapsed * 1e3 / total_frames
-            result["phase2"] = {"blit_ms_per_frame": round(blit_ms, 4), "fps_phase1_plus_phase2": round(1e3 / (phase1_ms + blit_ms), 2),
-                                "what": f"cvx_blit_segments per frame ({W}x{H} ARGB32 image, device resident), one launch per frame"}
+            # ... and as ONE launch over the step's frames (cvx_blit_segments_batch, F images left in HBM): 4 B gathered + 4 B stored per pixel
+            images = torch.empty((F, H, W), dtype=torch.int32, device=device)
+            ctx.blit_segments_batch(0, F, images.data_ptr())
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                ctx.blit_segments_batch(0, F, images.data_ptr())
+            ctx.synchronize()
+            batch_ms = (time.perf_counter() - t0) * 1e3 / (3 * F)
+            del images
+            result["phase2"] = {"blit_ms_per_frame": round(batch_ms, 4), "fps_phase1_plus_phase2": round(1e3 / (phase1_ms + batch_ms), 2),
+                                "blit_gbps": round(8.0 * W * H / (batch_ms * 1e-3) / 1e9, 1),
+                                "single_launch_blit_ms_per_frame": round(blit_ms, 4), "fps_phase1_plus_single_launch_blits": round(1e3 / (phase1_ms + blit_ms), 2),
+                                "what": f"cvx_blit_segments_batch over the {F} frames of a step ({W}x{H} ARGB32 images, device resident; blit_gbps = 8 B per screen pixel / time) "
+                                        f"and cvx_blit_segments, one launch per frame"}
         except Exception as e:  # noqa: BLE001
             result["phase2"] = {"error": str(e)}
 
@@ -438,11 +451,15 @@ def main():
             for k in range(min(K, 8)):
                 ctx.draw_packed(packed1[k], k % 2, gpu.DRAW_SYNC)
             ctx.draw_time_stats(reset=True)
+            per_frame = []
             t0 = time.perf_counter()
             for k in range(K):
+                t1 = time.perf_counter()
                 ctx.draw_packed(packed1[k], k % 2, gpu.DRAW_SYNC)
+                per_frame.append(time.perf_counter() - t1)
             dt = time.perf_counter() - t0
             k_ms1, n1 = ctx.draw_time_stats(reset=True)
+            worst = max(range(K), key=lambda k: per_frame[k])
             st = torch.cuda.Stream(device)
             ctx.set_stream(st.cuda_stream)
             events = []
@@ -460,6 +477,7 @@ def main():
             result["latency"] = {
                 "frames": 1, "ms": round(dt / K * 1e3, 4), "fps": round(K / dt, 1), "mrays": round(rays1 / dt / 1e6, 3),
                 "kernel_ms": round(k_ms1 / max(1, n1), 4),
+                "ms_max": round(per_frame[worst] * 1e3, 4), "fps_min": round(1.0 / per_frame[worst], 1), "worst_pose": (worst * POSE_STRIDE) % POSES,
                 "pipelined_2deep": {"ms": round(dt2 / K * 1e3, 4), "fps": round(K / dt2, 1), "mrays": round(rays1 / dt2 / 1e6, 3)},
                 "what": f"{K} single-frame cvx_draw_segments calls (first {K} poses of the bench), blocking / 2-deep CVX_DRAW_ASYNC over two raybuffer pairs; wall clock",
             }

@@ -68,6 +68,12 @@ struct cvx_context {
 	bool poolsExternal = false;
 	std::vector<LastDraw> last;
 	uint32_t *screen = nullptr;
+	uint32_t *screenBatch = nullptr; // cvx_blit_segments_batch without a caller buffer: screenBatchFrames images, grown on demand
+	int screenBatchFrames = 0;
+	void *blitParamsDev = nullptr;   // BlitParams of a batch (device) + their pinned staging copy
+	void *blitParamsPinned = nullptr;
+	int blitParamsCapacity = 0;
+	int blitBlockX = 64, blitBlockY = 4; // CVX_BLIT_BLOCK=XxY (diagnostics)
 	uint32_t *staging = nullptr;
 	size_t stagingBytes = 0;
 

@@ -56,6 +56,8 @@ void FreeRaybuffers(cvx_context *ctx)
 	ctx->poolLR.clear();
 	ctx->last.clear();
 	if (ctx->screen) { (void)hipFree(ctx->screen); ctx->screen = nullptr; }
+	if (ctx->screenBatch) { (void)hipFree(ctx->screenBatch); ctx->screenBatch = nullptr; }
+	ctx->screenBatchFrames = 0;
 	ctx->resX = ctx->resY = 0;
 }
 
@@ -447,6 +449,10 @@ int cvx_create(int device, cvx_context **out)
 			const int w = std::atoi(v);
 			if (w >= 64 && w <= 40960) { ctx->maxWaveMaskWords = w; ctx->maxWaveMaskWordsAuto = false; }
 		}
+		if (const char *v = std::getenv("CVX_BLIT_BLOCK")) { // diagnostics: thread block of the Phase-2 kernels, e.g. 16x16
+			int bx = 0, by = 0;
+			if (std::sscanf(v, "%dx%d", &bx, &by) == 2 && bx >= 1 && by >= 1 && bx * by >= 64 && bx * by <= 1024 && (bx * by) % 64 == 0) { ctx->blitBlockX = bx; ctx->blitBlockY = by; }
+		}
 		if (const char *v = std::getenv("CVX_RENDER_SM")) { ctx->renderStateMachine = std::atoi(v) != 0; }
 		if (const char *v = std::getenv("CVX_SM_THRESHOLD")) {
 			const int t = std::atoi(v);
@@ -473,6 +479,8 @@ void cvx_destroy(cvx_context *ctx)
 	if (ctx->devTiles) { (void)hipFree(ctx->devTiles); }
 	if (ctx->devCounters) { (void)hipFree(ctx->devCounters); }
 	if (ctx->staging) { (void)hipFree(ctx->staging); }
+	if (ctx->blitParamsDev) { (void)hipFree(ctx->blitParamsDev); }
+	if (ctx->blitParamsPinned) { (void)hipHostFree(ctx->blitParamsPinned); }
 	for (hipEvent_t e : ctx->evPairs) { (void)hipEventDestroy(e); }
 	for (auto &slot : ctx->upload) {
 		if (slot.pinned) { (void)hipHostFree(slot.pinned); }
@@ -773,14 +781,9 @@ int cvx_read_raybuffer(cvx_context *ctx, int bufferIndex, int which, int firstRa
 	return CVX_OK;
 }
 
-int cvx_blit_segments(cvx_context *ctx, int bufferIndex, void *dstHost)
+static void FillBlitParams(const cvx_context *ctx, int bufferIndex, cvxk::BlitParams &p)
 {
-	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
-	if (ctx->poolTD.empty() || bufferIndex < 0 || bufferIndex >= ctx->bufferCount) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "bad buffer selection"); }
 	const LastDraw &last = ctx->last[(size_t)bufferIndex];
-	if (!last.valid) { return Fail(ctx, CVX_ERR_NOT_READY, "nothing has been drawn into buffer %d", bufferIndex); }
-	CVX_HIP(ctx, hipSetDevice(ctx->device));
-	cvxk::BlitParams p;
 	p.vpX = last.vp[0];
 	p.vpY = last.vp[1];
 	for (int s = 0; s < 4; s++) {
@@ -794,7 +797,63 @@ int cvx_blit_segments(cvx_context *ctx, int bufferIndex, void *dstHost)
 	p.width = ctx->resX;
 	p.height = ctx->resY;
 	p.clearColor = 0u;
-	dim3 block(64, 4), grid((unsigned)((p.width + 63) / 64), (unsigned)((p.height + 3) / 4));
+}
+
+int cvx_blit_segments_batch(cvx_context *ctx, int firstBufferIndex, int frameCount, void *dstDevice, void **imagesDevice)
+{
+	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
+	if (imagesDevice) { *imagesDevice = nullptr; }
+	if (ctx->poolTD.empty() || frameCount <= 0 || firstBufferIndex < 0 || firstBufferIndex + frameCount > ctx->bufferCount) {
+		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "bad buffer range %d + %d of %d", firstBufferIndex, frameCount, ctx->bufferCount);
+	}
+	for (int f = 0; f < frameCount; f++) {
+		if (!ctx->last[(size_t)(firstBufferIndex + f)].valid) { return Fail(ctx, CVX_ERR_NOT_READY, "nothing has been drawn into buffer %d", firstBufferIndex + f); }
+	}
+	CVX_HIP(ctx, hipSetDevice(ctx->device));
+	const size_t imageBytes = (size_t)ctx->resX * (size_t)ctx->resY * 4;
+	uint32_t *images = static_cast<uint32_t *>(dstDevice);
+	if (!images) {
+		if (ctx->screenBatchFrames < frameCount) {
+			CVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+			if (ctx->screenBatch) { (void)hipFree(ctx->screenBatch); ctx->screenBatch = nullptr; ctx->screenBatchFrames = 0; }
+			CVX_HIP(ctx, hipMalloc((void **)&ctx->screenBatch, imageBytes * (size_t)frameCount));
+			ctx->screenBatchFrames = frameCount;
+		}
+		images = ctx->screenBatch;
+	}
+	if (ctx->blitParamsCapacity < frameCount) {
+		CVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		if (ctx->blitParamsDev) { (void)hipFree(ctx->blitParamsDev); ctx->blitParamsDev = nullptr; }
+		if (ctx->blitParamsPinned) { (void)hipHostFree(ctx->blitParamsPinned); ctx->blitParamsPinned = nullptr; }
+		ctx->blitParamsCapacity = 0;
+		CVX_HIP(ctx, hipMalloc(&ctx->blitParamsDev, sizeof(cvxk::BlitParams) * (size_t)frameCount));
+		CVX_HIP(ctx, hipHostMalloc(&ctx->blitParamsPinned, sizeof(cvxk::BlitParams) * (size_t)frameCount, hipHostMallocDefault));
+		ctx->blitParamsCapacity = frameCount;
+	} else {
+		CVX_HIP(ctx, hipStreamSynchronize(ctx->stream)); // the staging copy of the previous batch may still be read by its upload
+	}
+	cvxk::BlitParams *host = static_cast<cvxk::BlitParams *>(ctx->blitParamsPinned);
+	for (int f = 0; f < frameCount; f++) { FillBlitParams(ctx, firstBufferIndex + f, host[f]); }
+	CVX_HIP(ctx, hipMemcpyAsync(ctx->blitParamsDev, host, sizeof(cvxk::BlitParams) * (size_t)frameCount, hipMemcpyHostToDevice, ctx->stream));
+	dim3 block((unsigned)ctx->blitBlockX, (unsigned)ctx->blitBlockY);
+	dim3 grid((unsigned)((ctx->resX + ctx->blitBlockX - 1) / ctx->blitBlockX), (unsigned)((ctx->resY + ctx->blitBlockY - 1) / ctx->blitBlockY), (unsigned)frameCount);
+	hipLaunchKernelGGL(cvxk::blit_batch_kernel, grid, block, 0, ctx->stream, ctx->poolBaseTD, ctx->poolBaseLR, ctx->poolBytesTD / 4, ctx->poolBytesLR / 4, images,
+	                   static_cast<const cvxk::BlitParams *>(ctx->blitParamsDev), firstBufferIndex);
+	CVX_HIP(ctx, hipGetLastError());
+	if (imagesDevice) { *imagesDevice = images; }
+	return CVX_OK;
+}
+
+int cvx_blit_segments(cvx_context *ctx, int bufferIndex, void *dstHost)
+{
+	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
+	if (ctx->poolTD.empty() || bufferIndex < 0 || bufferIndex >= ctx->bufferCount) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "bad buffer selection"); }
+	const LastDraw &last = ctx->last[(size_t)bufferIndex];
+	if (!last.valid) { return Fail(ctx, CVX_ERR_NOT_READY, "nothing has been drawn into buffer %d", bufferIndex); }
+	CVX_HIP(ctx, hipSetDevice(ctx->device));
+	cvxk::BlitParams p;
+	FillBlitParams(ctx, bufferIndex, p);
+	dim3 block((unsigned)ctx->blitBlockX, (unsigned)ctx->blitBlockY), grid((unsigned)((p.width + ctx->blitBlockX - 1) / ctx->blitBlockX), (unsigned)((p.height + ctx->blitBlockY - 1) / ctx->blitBlockY));
 	hipLaunchKernelGGL(cvxk::blit_kernel, grid, block, 0, ctx->stream, ctx->poolTD[(size_t)bufferIndex], ctx->poolLR[(size_t)bufferIndex], ctx->screen, p);
 	CVX_HIP(ctx, hipGetLastError());
 	if (dstHost) {

@@ -1184,13 +1184,8 @@ struct BlitParams {
 	uint32_t clearColor;
 };
 
-__global__ void blit_kernel(const uint32_t *__restrict__ poolTD, const uint32_t *__restrict__ poolLR, uint32_t *__restrict__ screen, BlitParams p)
+__device__ __forceinline__ uint32_t blit_pixel(const uint32_t *__restrict__ poolTD, const uint32_t *__restrict__ poolLR, const BlitParams &p, int px, int py)
 {
-	const int px = blockIdx.x * blockDim.x + threadIdx.x;
-	const int py = blockIdx.y * blockDim.y + threadIdx.y;
-	if (px >= p.width || py >= p.height) {
-		return;
-	}
 	const float cx = (float)px + 0.5f, cy = (float)py + 0.5f;
 	uint32_t color = p.clearColor;
 	for (int s = 0; s < 4; s++) {
@@ -1217,7 +1212,33 @@ __global__ void blit_kernel(const uint32_t *__restrict__ poolTD, const uint32_t 
 			break;
 		}
 	}
-	screen[(size_t)py * (size_t)p.width + (size_t)px] = color;
+	return color;
+}
+
+__global__ void blit_kernel(const uint32_t *__restrict__ poolTD, const uint32_t *__restrict__ poolLR, uint32_t *__restrict__ screen, BlitParams p)
+{
+	const int px = blockIdx.x * blockDim.x + threadIdx.x;
+	const int py = blockIdx.y * blockDim.y + threadIdx.y;
+	if (px >= p.width || py >= p.height) {
+		return;
+	}
+	screen[(size_t)py * (size_t)p.width + (size_t)px] = blit_pixel(poolTD, poolLR, p, px, py);
+}
+
+// Phase 2 of a whole batch in one launch (blockIdx.z = frame): buffer firstBuffer + f -> image f of `screens`.  All raybuffers of a
+// kind are one allocation, strideTD / strideLR = uint32 words per buffer.
+__global__ void blit_batch_kernel(const uint32_t *__restrict__ poolBaseTD, const uint32_t *__restrict__ poolBaseLR, size_t strideTD, size_t strideLR,
+                                  uint32_t *__restrict__ screens, const BlitParams *__restrict__ params, int firstBuffer)
+{
+	const int f = blockIdx.z;
+	const BlitParams &p = params[f];
+	const int px = blockIdx.x * blockDim.x + threadIdx.x;
+	const int py = blockIdx.y * blockDim.y + threadIdx.y;
+	if (px >= p.width || py >= p.height) {
+		return;
+	}
+	const size_t b = (size_t)(firstBuffer + f);
+	screens[((size_t)f * (size_t)p.height + (size_t)py) * (size_t)p.width + (size_t)px] = blit_pixel(poolBaseTD + b * strideTD, poolBaseLR + b * strideLR, p, px, py);
 }
 
 // ---------------------------------------------------------------------------

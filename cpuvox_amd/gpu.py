@@ -26,7 +26,7 @@ DRAW_ASYNC = 1
 EXPORTS = [
     "cvx_create", "cvx_destroy", "cvx_last_error", "cvx_set_stream", "cvx_world_upload", "cvx_set_resolution",
     "cvx_set_buffer_count", "cvx_draw_segments", "cvx_draw_segments_batch", "cvx_set_shard", "cvx_synchronize",
-    "cvx_clear_raybuffer", "cvx_read_raybuffer", "cvx_blit_segments", "cvx_raybuffer_device_ptr",
+    "cvx_clear_raybuffer", "cvx_read_raybuffer", "cvx_blit_segments", "cvx_blit_segments_batch", "cvx_raybuffer_device_ptr",
     "cvx_screen_device_ptr", "cvx_last_draw_ms", "cvx_enable_counters", "cvx_get_counters",
     "cvx_get_raybuffer_layout", "cvx_selftest_math", "cvx_version", "cvx_bind_raybuffers", "cvx_draw_time_stats", "cvx_debug_section_cycles", "cvx_debug_occupancy", "cvx_copy_rows", "cvx_draw_segments_placed",
     "cvx_world_downsample", "cvx_world_build_lods", "cvx_free", "cvx_debug_section_histogram",
@@ -60,6 +60,23 @@ def lib_path() -> str:
     return os.environ.get("CVX_GPU_LIB") or os.path.join(_HERE, "libcpuvox_gpu.so")
 
 
+def _load_torch_hip_runtime_first() -> None:
+    """One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64 under unversioned file names; its
+    libraries ask for them by those names, so a copy of /opt/rocm's runtime that this library pulled in earlier (SONAME
+    libamdhip64.so.7) is not recognised as the same thing, a second runtime is loaded and finds no GPU ("No HIP GPUs are
+    available").  The other order works: the loader matches this library's libamdhip64.so.7 against the SONAME of torch's copy.
+    Hosts that use both (bench.py, cpuvox_amd.dist, the tests that hand torch tensors to the C ABI) therefore need torch loaded
+    first; without torch installed nothing happens.  CVX_NO_TORCH_PRELOAD=1 skips this (a host that never touches torch)."""
+    import sys
+
+    if "torch" in sys.modules or os.environ.get("CVX_NO_TORCH_PRELOAD"):
+        return
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+
+
 def lib() -> C.CDLL:
     """Load libcpuvox_gpu.so (built in-tree by cpuvox_amd/csrc/Makefile); fails loudly when missing."""
     global _lib
@@ -67,6 +84,7 @@ def lib() -> C.CDLL:
         path = lib_path()
         if not os.path.exists(path):
             raise RuntimeError(f"{path} missing: the HIP extension is required (build with `make -C cpuvox_amd/csrc`); there is no CPU fallback")
+        _load_torch_hip_runtime_first()
         L = C.CDLL(path)
         L.cvx_version.restype = C.c_char_p
         L.cvx_last_error.restype = C.c_char_p
@@ -86,6 +104,7 @@ def lib() -> C.CDLL:
         L.cvx_clear_raybuffer.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint32]
         L.cvx_read_raybuffer.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.cvx_blit_segments.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.cvx_blit_segments_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
         L.cvx_raybuffer_device_ptr.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
         L.cvx_screen_device_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
         L.cvx_last_draw_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
@@ -297,6 +316,14 @@ class Context:
         out = np.empty((self.height, self.width), dtype=np.uint32)
         self._check(lib().cvx_blit_segments(self._h, buffer_index, out.ctypes.data))
         return out
+
+    def blit_segments_batch(self, first_buffer: int, frame_count: int, dst_device: int | None = None) -> int:
+        """Phase 2 of `frame_count` frames (buffers first_buffer ..) in ONE launch, asynchronous on the context's stream.  Image f goes to
+        dst_device + f * H * W * 4 (a device address, e.g. a torch tensor's data_ptr()), or into an array the context owns; returns
+        the device address of image 0."""
+        p = C.c_void_p()
+        self._check(lib().cvx_blit_segments_batch(self._h, first_buffer, frame_count, C.c_void_p(dst_device) if dst_device else None, C.byref(p)))
+        return p.value
 
     def raybuffer_device_ptr(self, buffer_index: int, which: int):
         p = C.c_void_p()

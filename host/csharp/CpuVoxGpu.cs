@@ -82,6 +82,7 @@ namespace CpuVox.Gpu
 		[DllImport(Lib)] public static extern int cvx_clear_raybuffer(IntPtr ctx, int bufferIndex, int which, uint argb);
 		[DllImport(Lib)] public static extern int cvx_read_raybuffer(IntPtr ctx, int bufferIndex, int which, int firstRay, int rayCount, void* dst);
 		[DllImport(Lib)] public static extern int cvx_blit_segments(IntPtr ctx, int bufferIndex, void* dstHost);
+		[DllImport(Lib)] public static extern int cvx_blit_segments_batch(IntPtr ctx, int firstBufferIndex, int frameCount, void* dstDevice, out IntPtr imagesDevice);
 		[DllImport(Lib)] public static extern int cvx_bind_raybuffers(IntPtr ctx, void* topDown, long topDownBytes, void* leftRight, long leftRightBytes);
 		[DllImport(Lib)] public static extern int cvx_raybuffer_device_ptr(IntPtr ctx, int bufferIndex, int which, out IntPtr ptr, out long bytes);
 		[DllImport(Lib)] public static extern int cvx_screen_device_ptr(IntPtr ctx, out IntPtr ptr, out long bytes);
@@ -160,6 +161,9 @@ namespace CpuVox.Gpu
 
 		/// <summary>RenderManager.BlitSegments + RayBufferBlit.shader: W*H ARGB32 pixels, row 0 = bottom.</summary>
 		public void BlitSegments(int bufferIndex, void* dstArgb32) { Check(Native.cvx_blit_segments(ctx, bufferIndex, dstArgb32)); }
+
+		/// <summary>Phase 2 of a batch in one launch; the images stay in device memory (returns the address of image 0).</summary>
+		public IntPtr BlitSegmentsBatch(int firstBufferIndex, int frameCount, void* dstDevice = null) { Check(Native.cvx_blit_segments_batch(ctx, firstBufferIndex, frameCount, dstDevice, out IntPtr images)); return images; }
 
 		/// <summary>Rows of a raybuffer in the reference's layout (RayBuffer.Native.GetRayColumn, RayBuffer.cs:121-128).</summary>
 		public void ReadRayBuffer(int bufferIndex, int which, int firstRay, int rayCount, void* dst) { Check(Native.cvx_read_raybuffer(ctx, bufferIndex, which, firstRay, rayCount, dst)); }

@@ -204,6 +204,15 @@ int cvx_read_raybuffer(cvx_context *ctx, int bufferIndex, int which, int firstRa
  */
 int cvx_blit_segments(cvx_context *ctx, int bufferIndex, void *dstHost);
 
+/*
+ * Phase 2 for the frames of a batch in ONE launch: BlitSegments (RenderManager.cs:199-256) of the last draws into buffers
+ * firstBufferIndex .. firstBufferIndex + frameCount - 1 (what cvx_draw_segments_batch rendered), image f into
+ * dstDevice + f * W * H * 4 bytes (device memory; NULL = an array the context owns, grown on demand).  Asynchronous on
+ * the context's stream; *imagesDevice (may be NULL) receives the address of image 0.  Same pixels as frameCount calls of
+ * cvx_blit_segments.
+ */
+int cvx_blit_segments_batch(cvx_context *ctx, int firstBufferIndex, int frameCount, void *dstDevice, void **imagesDevice);
+
 /* Use caller-owned device memory for the raybuffers (e.g. torch tensors that a RCCL collective
  * operates on).  Sizes: bufferCount * tileCapacity * tileBytes per kind (cvx_get_raybuffer_layout),
  * 256-byte aligned.  Buffer b of a kind starts at b * tileCapacity * tileBytes.  The context never

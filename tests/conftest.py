@@ -9,6 +9,15 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+# One HIP runtime per process: torch's bundled copy has to be loaded before libcpuvox_gpu.so pulls in /opt/rocm's (see
+# cpuvox_amd.gpu._load_torch_hip_runtime_first); tests hand torch tensors to the C ABI, so make the order explicit here instead of
+# depending on which test file happens to be collected first.
+try:
+    import torch  # noqa: F401,E402
+except ImportError:
+    pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
