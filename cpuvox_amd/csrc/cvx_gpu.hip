@@ -111,6 +111,14 @@ int EnsureScratch(cvx_context *ctx, size_t frames, size_t tiles)
 	return CVX_OK;
 }
 
+#ifdef CVX_TILE_TIMES /* diagnostic build (tools/lpt_oracle.py): which tile each launched wave belongs to; after a blocking draw the clock ticks of
+                         every tile (sum over its waves) are written to $CVX_TILE_TIMES_OUT as one float per tile, in BuildFrame's tile order */
+std::vector<uint32_t> g_waveSource;
+size_t g_sourceTiles = 0;
+unsigned long long *g_tileTimesDev = nullptr;
+size_t g_tileTimesCap = 0;
+#endif
+
 // Launch-order heuristic only (never affects results): DDA column visits the tile's middle ray would make
 // if nothing occluded it = path length inside the world's XZ box (capped by far clip) * (|dx| + |dz|).
 float EstimateTileCost(const cvx_context *ctx, const DevFrame &F, const DevSegment &S, int tileInSeg)
@@ -379,6 +387,15 @@ int Launch(cvx_context *ctx, int frameCount, int flags)
 	if (ctx->countersEnabled) {
 		CVX_HIP(ctx, hipMemsetAsync(ctx->devCounters, 0, sizeof(DevCounters), ctx->stream));
 	}
+#ifdef CVX_TILE_TIMES
+	if (nTiles > g_tileTimesCap) {
+		CVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		if (g_tileTimesDev) { (void)hipFree(g_tileTimesDev); }
+		g_tileTimesCap = nTiles + nTiles / 2;
+		CVX_HIP(ctx, hipMalloc((void **)&g_tileTimesDev, g_tileTimesCap * sizeof(unsigned long long)));
+		CVX_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(cvxk::g_tileTimes), &g_tileTimesDev, sizeof g_tileTimesDev));
+	}
+#endif
 	hipEvent_t evStart = nullptr, evStop = nullptr;
 	rc = NextEventPair(ctx, evStart, evStop);
 	if (rc != CVX_OK) { return rc; }
@@ -402,6 +419,20 @@ int Launch(cvx_context *ctx, int frameCount, int flags)
 	CVX_HIP(ctx, hipEventRecord(evStop, ctx->stream));
 	if (!(flags & CVX_DRAW_ASYNC)) {
 		CVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+#ifdef CVX_TILE_TIMES
+		if (const char *path = std::getenv("CVX_TILE_TIMES_OUT")) {
+			if (nTiles && !ctx->countersEnabled && g_waveSource.size() == nTiles) {
+				std::vector<unsigned long long> ticks(nTiles);
+				CVX_HIP(ctx, hipMemcpy(ticks.data(), g_tileTimesDev, nTiles * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+				std::vector<float> perTile(g_sourceTiles, 0.0f);
+				for (size_t i = 0; i < nTiles; i++) { perTile[g_waveSource[i]] += (float)ticks[i]; }
+				if (FILE *fh = std::fopen(path, "wb")) {
+					std::fwrite(perTile.data(), sizeof(float), perTile.size(), fh);
+					std::fclose(fh);
+				}
+			}
+		}
+#endif
 	}
 	return CVX_OK;
 }
@@ -627,6 +658,15 @@ int DrawBatch(cvx_context *ctx, int frameCount, const cvx_segment_data *segments
 			order[i] = (uint32_t)i;
 			if (ctx->hostTileWords[i] > ctx->maskWordsNeeded) { ctx->maskWordsNeeded = ctx->hostTileWords[i]; }
 		}
+#ifdef CVX_TILE_TIMES
+		if (const char *path = std::getenv("CVX_TILE_COST_FILE")) { // diagnostic build only (tools/lpt_oracle.py): launch order from measured costs, one float per tile
+			if (FILE *fh = std::fopen(path, "rb")) {
+				std::vector<float> measured(n);
+				if (n > 0 && std::fread(measured.data(), sizeof(float), n, fh) == n && std::fgetc(fh) == EOF) { ctx->hostTileCost = measured; }
+				std::fclose(fh);
+			}
+		}
+#endif
 		const std::vector<float> &cost = ctx->hostTileCost;
 		std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
 		if (const char *v = std::getenv("CVX_TILE_ORDER")) { // diagnostics: how much the launch order matters
@@ -681,6 +721,10 @@ int DrawBatch(cvx_context *ctx, int frameCount, const cvx_segment_data *segments
 		}
 		std::vector<DevTile> sorted;
 		sorted.reserve(n * (size_t)split);
+#ifdef CVX_TILE_TIMES
+		g_waveSource.clear();
+		g_sourceTiles = n;
+#endif
 		int ldsWords = 1; // words * lanes of the largest wave
 		for (size_t i = 0; i < n; i++) {
 			DevTile t = ctx->hostTiles[order[i]];
@@ -691,11 +735,17 @@ int DrawBatch(cvx_context *ctx, int frameCount, const cvx_segment_data *segments
 			ldsWords = std::max(ldsWords, words * lanesPerWave);
 			if (tileSplit == 1) {
 				sorted.push_back(t);
+#ifdef CVX_TILE_TIMES
+				g_waveSource.push_back(order[i]);
+#endif
 				continue;
 			}
 			for (int k = 0; k < tileSplit; k++) {
 				t.lanes = (k * lanesPerWave) | (lanesPerWave << 8);
 				sorted.push_back(t);
+#ifdef CVX_TILE_TIMES
+				g_waveSource.push_back(order[i]);
+#endif
 			}
 		}
 		ctx->ldsWordsNeeded = ldsWords;

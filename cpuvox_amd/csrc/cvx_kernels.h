@@ -403,6 +403,10 @@ struct ProfLane {};
 #define CVX_WAITPROBE(n) ((void)0)
 #endif
 
+#ifdef CVX_TILE_TIMES /* diagnostic build: clock ticks each launched wave lived, for the launch-order experiment (tools/lpt_oracle.py) */
+__device__ unsigned long long *g_tileTimes;
+#endif
+
 struct LaneCounters {
 	unsigned int S, E, C, P;
 	unsigned int lod[6];
@@ -1006,6 +1010,9 @@ __global__ __launch_bounds__(CVX_WAVE, CVX_WAVES_PER_SIMD) void render_kernel(co
 {
 	extern __shared__ uint32_t lds[];
 	const int lane = threadIdx.x;
+#ifdef CVX_TILE_TIMES
+	const unsigned long long tileStart_ = __builtin_amdgcn_s_memtime();
+#endif
 	const DevTile tile = tiles[blockIdx.x];
 	const DevFrame &F = frames[tile.frame];
 	const DevSegment &S = F.seg[tile.seg];
@@ -1092,6 +1099,9 @@ __global__ __launch_bounds__(CVX_WAVE, CVX_WAVES_PER_SIMD) void render_kernel(co
 		}
 #endif
 	}
+#endif
+#ifdef CVX_TILE_TIMES
+	if (!COUNT && lane == 0 && g_tileTimes) { g_tileTimes[blockIdx.x] = __builtin_amdgcn_s_memtime() - tileStart_; }
 #endif
 	if (COUNT) {
 		cnt.P += skyPixels;
