@@ -659,6 +659,12 @@ int DrawBatch(cvx_context *ctx, int frameCount, const cvx_segment_data *segments
 			if (ctx->hostTileWords[i] > ctx->maskWordsNeeded) { ctx->maskWordsNeeded = ctx->hostTileWords[i]; }
 		}
 #ifdef CVX_TILE_TIMES
+		if (const char *path = std::getenv("CVX_TILE_EST_OUT")) { // the library's own estimates, one float per tile
+			if (FILE *fh = std::fopen(path, "wb")) {
+				std::fwrite(ctx->hostTileCost.data(), sizeof(float), n, fh);
+				std::fclose(fh);
+			}
+		}
 		if (const char *path = std::getenv("CVX_TILE_COST_FILE")) { // diagnostic build only (tools/lpt_oracle.py): launch order from measured costs, one float per tile
 			if (FILE *fh = std::fopen(path, "rb")) {
 				std::vector<float> measured(n);

@@ -109,3 +109,46 @@ for shift, label in ((0, "same batch through the mapping (check)"), (1000, "same
     rel = float(np.median(np.abs(own - costs) / np.maximum(own, 1.0))) if own.size == costs.size else float("nan")
     print(f"{label}: estimate order {est:.3f} ms, order from the other batch's measured costs {hist:.3f} ms ({100.0 * (hist / est - 1.0):+.1f} %), tiles {costs.size}, "
           f"correlation with its own measured costs {corr:.4f}, median relative difference {rel:.3f}")
+
+
+# ---- the library's estimate, rescaled per (frame, segment) by what the NEIGHBOURING pose's segment measured (ticks per estimated step):
+# keeps the estimate's ranking inside a segment (an upper bound per ray), corrects the systematic part (pitch, height, how much is drawn)
+def estimates_of(pk):
+    os.environ["CVX_TILE_EST_OUT"] = "/tmp/cvx_tile_est.bin"
+    ctx.draw_packed(pk, 0)
+    del os.environ["CVX_TILE_EST_OUT"]
+    return np.fromfile("/tmp/cvx_tile_est.bin", dtype=np.float32)
+
+
+est_a = estimates_of(packed)
+print(f"estimate vs measured ticks, this batch: correlation {float(np.corrcoef(est_a, ticks)[0, 1]):.4f}")
+for shift, label in ((27, "neighbouring pose"), (135, "five poses away")):
+    other = frames_from(first + shift)
+    packed_b = ctx.pack_batch(other)
+    est_b = estimates_of(packed_b)
+    tp_a, tp_b = tiles_per_frame(frames), tiles_per_frame(other)
+    pred = np.zeros_like(est_b)
+    ca = cb = 0
+    glob = ticks.sum() / max(1.0, est_a.sum())
+    for fa, fb in zip(tp_a, tp_b):
+        for na, nb in zip(fa, fb):
+            ta, ea = ticks[ca:ca + na], est_a[ca:ca + na]
+            ca += na
+            ratio = ta.sum() / ea.sum() if na and ea.sum() > 0 else glob
+            pred[cb:cb + nb] = est_b[cb:cb + nb] * ratio
+            cb += nb
+
+    def draw_b2(n=3):
+        ms = []
+        for _ in range(n):
+            ctx.draw_packed(packed_b, 0)
+            ms.append(ctx.last_draw_ms())
+        return min(ms)
+
+    os.environ.pop("CVX_TILE_COST_FILE", None)
+    e0 = draw_b2()
+    pred.astype(np.float32).tofile("/tmp/cvx_tile_costs_c.bin")
+    os.environ["CVX_TILE_COST_FILE"] = "/tmp/cvx_tile_costs_c.bin"
+    e1 = draw_b2()
+    os.environ.pop("CVX_TILE_COST_FILE", None)
+    print(f"{label}: estimate order {e0:.3f} ms, estimate x per-segment ticks/step of the other batch {e1:.3f} ms ({100.0 * (e1 / e0 - 1.0):+.1f} %)")
