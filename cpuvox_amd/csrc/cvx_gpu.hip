@@ -147,7 +147,10 @@ float EstimateTileCost(const cvx_context *ctx, const DevFrame &F, const DevSegme
 	if (t1 <= t0) { return 0.f; }
 	// (weighting the far part by its LOD -- a step at LOD l crosses 2^l voxels -- was measured and orders the launch slightly
 	// worse: 33.3 vs 33.05 ms; with this order the wave slots stay ~100 % occupied to the end of the launch, random order costs 19 %)
-	return (t1 - t0) * (std::fabs(dx) + std::fabs(dz));
+	// + the pixels a ray of the tile can write: the measured life of a wave goes with column visits AND pixels (a steep view writes its whole window
+	// within few columns).  One pixel = one column visit orders a 512-frame launch 1 % better than the visits alone (32.50 vs 32.83 ms); the clock ticks
+	// every tile really took would be worth 6.7 %, but only the exact ones (profiles/r02_experiments.md).  CVX_TILE_COST_PIXELS overrides the weight.
+	return (t1 - t0) * (std::fabs(dx) + std::fabs(dz)) + ctx->tileCostPixelWeight * (float)(S.omax - S.omin + 1);
 }
 
 // Fills SegmentContext[4] the way DrawSegments does (RenderManager.cs:281-318)
@@ -483,6 +486,10 @@ int cvx_create(int device, cvx_context **out)
 		if (const char *v = std::getenv("CVX_BLIT_BLOCK")) { // diagnostics: thread block of the Phase-2 kernels, e.g. 16x16
 			int bx = 0, by = 0;
 			if (std::sscanf(v, "%dx%d", &bx, &by) == 2 && bx >= 1 && by >= 1 && bx * by >= 64 && bx * by <= 1024 && (bx * by) % 64 == 0) { ctx->blitBlockX = bx; ctx->blitBlockY = by; }
+		}
+		if (const char *v = std::getenv("CVX_TILE_COST_PIXELS")) { // diagnostics
+			const float w = (float)std::atof(v);
+			if (w >= 0.f && w <= 100.f) { ctx->tileCostPixelWeight = w; }
 		}
 		if (const char *v = std::getenv("CVX_RENDER_SM")) { ctx->renderStateMachine = std::atoi(v) != 0; }
 		if (const char *v = std::getenv("CVX_SM_THRESHOLD")) {

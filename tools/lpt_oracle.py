@@ -152,3 +152,22 @@ for shift, label in ((27, "neighbouring pose"), (135, "five poses away")):
     e1 = draw_b2()
     os.environ.pop("CVX_TILE_COST_FILE", None)
     print(f"{label}: estimate order {e0:.3f} ms, estimate x per-segment ticks/step of the other batch {e1:.3f} ms ({100.0 * (e1 / e0 - 1.0):+.1f} %)")
+
+
+# ---- data for offline analysis (which tiles the estimate ranks too low)
+if os.environ.get("CVX_LPT_DUMP"):
+    tp = tiles_per_frame(frames)
+    fidx, sidx, tidx = [], [], []
+    for i, per_seg in enumerate(tp):
+        for s_, n_ in enumerate(per_seg):
+            fidx += [i] * n_
+            sidx += [s_] * n_
+            tidx += list(range(n_))
+    poses = []
+    for g in range(first, first + frames_n):
+        t = ((g * 37) % 1000) / 1000 * host.BENCHMARK_PATH_LENGTH
+        pos, eul = host.sample_benchmark_path(t, ws.dims)
+        poses.append(list(pos) + list(eul))
+    np.savez_compressed(os.environ["CVX_LPT_DUMP"], est=est_a, ticks=ticks, frame=np.array(fidx, dtype=np.int32), seg=np.array(sidx, dtype=np.int8),
+                        tile=np.array(tidx, dtype=np.int16), poses=np.array(poses, dtype=np.float32), tiles_per_seg=np.array(tp, dtype=np.int32))
+    print("dumped", os.environ["CVX_LPT_DUMP"])
