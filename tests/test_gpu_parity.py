@@ -170,7 +170,7 @@ def test_batch_blit_equals_single_blits():
     both into a caller's device buffer (a torch tensor) and into the array the context owns."""
     import torch
 
-    names = ["proc256_t0_lod8", "proc256_t04_lod8", "proc256_t075_lod8", "proc256_up_lod4"]
+    names = ["proc256_t0_lod8", "proc256_t04_lod8", "proc256_t075_lod8", "proc256_t075_lod1"]  # one world, one resolution
     frames = []
     for n in names:
         ws, fr, W, H = scenes.scene_frame(n)
@@ -258,6 +258,31 @@ def test_sub_tile_split_is_invisible(split, monkeypatch):
             o_td, o_lr, oc = O.draw_segments(ws, fr, W, H, clear=CLEAR)
             _compare(f"{name} split {split}", fr, g_td, g_lr, o_td, o_lr)
             assert (c.S, c.E, c.C, c.P, c.R) == (oc.S, oc.E, oc.C, oc.P, oc.R)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.parametrize("order", ["reverse", "random", "pixels0", "pixels8"])
+def test_launch_order_is_invisible(order, monkeypatch):
+    """The tiles of a batch are launched longest-first by an estimate (column visits + window pixels, EstimateTileCost); the estimate and
+    the order are scheduling only -- every tile writes its own rows -- so any order gives the same raybuffers."""
+    if order.startswith("pixels"):
+        monkeypatch.setenv("CVX_TILE_COST_PIXELS", order[len("pixels"):])
+    else:
+        monkeypatch.setenv("CVX_TILE_ORDER", order)
+    names = ["proc256_t0_lod8", "proc256_t04_lod8", "proc256_t075_lod8", "proc256_t075_lod1"]  # one world, one resolution
+    frames = [scenes.scene_frame(n)[1] for n in names]
+    ws, _, W, H = scenes.scene_frame(names[0])
+    ctx = gpu.Context(0, buffer_count=len(frames))
+    try:
+        ctx.upload_world(ws)
+        ctx.set_resolution(W, H)
+        for b in range(len(frames)):
+            ctx.clear_raybuffers(b, CLEAR)
+        ctx.draw_segments_batch(frames, 0)
+        for b, (n, fr) in enumerate(zip(names, frames)):
+            o_td, o_lr, _ = O.draw_segments(ws, fr, W, H, clear=CLEAR)
+            _compare(f"{n} order {order}", fr, ctx.read_raybuffer(b, gpu.RAYBUFFER_TOPDOWN), ctx.read_raybuffer(b, gpu.RAYBUFFER_LEFTRIGHT), o_td, o_lr)
     finally:
         ctx.close()
 

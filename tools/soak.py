@@ -35,7 +35,16 @@ for world, W, H, lod_error in (("proc1024", 1920, 1080, 1.0), ("proc512", 1280, 
         n_td, n_lr = scenes.used_rows(fr)
         ok = np.array_equal(g_td[:n_td], o_td[:n_td]) and np.array_equal(g_lr[:n_lr], o_lr[:n_lr]) and \
             (c.S, c.E, c.C, c.P, c.R) == (oc.S, oc.E, oc.C, oc.P, oc.R)
+        # ... and the rendering build (render_kernel<false>; render_sm_kernel under CVX_RENDER_SM=1), which leaves a finished ray at other points
+        ctx.enable_counters(False)
+        ctx.clear_raybuffers(1, CLEAR)
+        ctx.draw_segments(fr, 1)
+        r_td = ctx.read_raybuffer(1, gpu.RAYBUFFER_TOPDOWN)
+        r_lr = ctx.read_raybuffer(1, gpu.RAYBUFFER_LEFTRIGHT)
+        ok = ok and np.array_equal(r_td[:n_td], o_td[:n_td]) and np.array_equal(r_lr[:n_lr], o_lr[:n_lr])
         total += 1
+        if (i + 1) % 1000 == 0:
+            print(f"  {world}: {i + 1} poses, {bad} mismatches so far", flush=True)
         if not ok:
             bad += 1
             print("MISMATCH", world, W, H, pos, eul)
