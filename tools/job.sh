@@ -1,1 +1,1 @@
-bash tools/variants.sh "libcpuvox_gpu.so libcpuvox_gpu_notm.so libcpuvox_gpu_tdp4.so libcpuvox_gpu_tdp8.so libcpuvox_gpu_o2.so" --frames 512 2>&1 | grep -v "^Traceback\|^  File\|^    \|^json"
+bash tools/variants.sh "libcpuvox_gpu_h2.so libcpuvox_gpu_h3.so" --frames 512 2>&1 | grep -v "^Traceback\|^  File\|^    \|^json"
