@@ -1,1 +1,2 @@
-bash tools/variants.sh "libcpuvox_gpu_h2.so libcpuvox_gpu_h3.so" --frames 512 2>&1 | grep -v "^Traceback\|^  File\|^    \|^json"
+bash tools/profile_round.sh r02g > gpurun_out/profile_round_r02g.log 2>&1
+tail -5 gpurun_out/profile_round_r02g.log
