@@ -11,7 +11,38 @@ import oraclelib as O  # noqa: E402
 import scenes  # noqa: E402
 from cpuvox_amd import gpu  # noqa: E402
 
-poses = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+poses = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1] != "bench" else 100
+if len(sys.argv) > 1 and sys.argv[1] == "bench":
+    # every pose of the benchmark path (the 1000 samples bench.py cycles through) on the benchmark world at the benchmark resolution, as ONE
+    # batch per 100 poses through the rendering build (what bench.py times) -- raybuffers against the oracle
+    from cpuvox_amd import host
+
+    W, H = 1920, 1080
+    ws = scenes.load_world("proc2048")
+    lods, far = host.setup_lods(host.camera_pose((0, 0, 0), (0, 0, 0), W, H), ws.max_dimension, W, H, 1.0)
+    ctx = gpu.Context(0, buffer_count=100)
+    ctx.upload_world(ws)
+    ctx.set_resolution(W, H)
+    bad = 0
+    for first in range(0, 1000, 100):
+        frames = []
+        for i in range(first, first + 100):
+            pos, eul = host.sample_benchmark_path(i / 1000 * host.BENCHMARK_PATH_LENGTH, ws.dims)
+            frames.append(host.setup_frame(host.camera_pose(pos, eul, W, H), lods, far, W, H, ws.dims[1]))
+        for b in range(100):
+            ctx.clear_raybuffers(b, 0x9314FFFF)
+        ctx.draw_segments_batch(frames, 0)
+        for b, fr in enumerate(frames):
+            o_td, o_lr, _ = O.draw_segments(ws, fr, W, H, clear=0x9314FFFF, counters=False)
+            n_td, n_lr = scenes.used_rows(fr)
+            g_td = ctx.read_raybuffer(b, gpu.RAYBUFFER_TOPDOWN, 0, n_td)
+            g_lr = ctx.read_raybuffer(b, gpu.RAYBUFFER_LEFTRIGHT, 0, n_lr)
+            if not (np.array_equal(g_td, o_td[:n_td]) and np.array_equal(g_lr, o_lr[:n_lr])):
+                bad += 1
+                print("MISMATCH benchmark pose", first + b)
+        print(f"benchmark poses {first}..{first + 99}: {bad} mismatches so far", flush=True)
+    print(f"soak (benchmark path, proc2048 @ {W}x{H}): 1000 poses, {bad} mismatches")
+    sys.exit(1 if bad else 0)
 CLEAR = 0x9314FFFF
 rng = np.random.default_rng(20261003)
 bad = total = 0
