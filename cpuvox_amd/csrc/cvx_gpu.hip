@@ -119,11 +119,11 @@ unsigned long long *g_tileTimesDev = nullptr;
 size_t g_tileTimesCap = 0;
 #endif
 
-// Launch-order heuristic only (never affects results): DDA column visits the tile's middle ray would make
-// if nothing occluded it = path length inside the world's XZ box (capped by far clip) * (|dx| + |dz|).
-float EstimateTileCost(const cvx_context *ctx, const DevFrame &F, const DevSegment &S, int tileInSeg)
+// Launch-order heuristic only (never affects results): DDA column visits a ray of the segment would make if nothing occluded it = path length
+// inside the world's XZ box (capped by far clip) * (|dx| + |dz|); an upper bound of the ray's steps.
+float RayColumnVisits(const cvx_context *ctx, const DevFrame &F, const DevSegment &S, int planeRayIndex)
 {
-	float t = ((float)(tileInSeg * CVX_WAVE + CVX_WAVE / 2)) / (float)(S.rayCount > 0 ? S.rayCount : 1);
+	float t = (float)planeRayIndex / (float)(S.rayCount > 0 ? S.rayCount : 1);
 	if (t > 1.f) { t = 1.f; }
 	float dx = S.rayMinX + t * (S.rayMaxX - S.rayMinX);
 	float dz = S.rayMinZ + t * (S.rayMaxZ - S.rayMinZ);
@@ -145,12 +145,22 @@ float EstimateTileCost(const cvx_context *ctx, const DevFrame &F, const DevSegme
 		if (tb < t1) { t1 = tb; }
 	}
 	if (t1 <= t0) { return 0.f; }
-	// (weighting the far part by its LOD -- a step at LOD l crosses 2^l voxels -- was measured and orders the launch slightly
-	// worse: 33.3 vs 33.05 ms; with this order the wave slots stay ~100 % occupied to the end of the launch, random order costs 19 %)
-	// + the pixels a ray of the tile can write: the measured life of a wave goes with column visits AND pixels (a steep view writes its whole window
-	// within few columns).  One pixel = one column visit orders a 512-frame launch 1 % better than the visits alone (32.50 vs 32.83 ms); the clock ticks
-	// every tile really took would be worth 6.7 %, but only the exact ones (profiles/r02_experiments.md).  CVX_TILE_COST_PIXELS overrides the weight.
-	return (t1 - t0) * (std::fabs(dx) + std::fabs(dz)) + ctx->tileCostPixelWeight * (float)(S.omax - S.omin + 1);
+	// (weighting the far part by its LOD -- a step at LOD l crosses 2^l voxels -- was measured and orders the launch slightly worse)
+	return (t1 - t0) * (std::fabs(dx) + std::fabs(dz));
+}
+
+// A wave lives as long as its longest ray, and the path through the world box changes fast from ray to ray near the box's corners and where rays
+// start to miss it: the tile's estimate is the LONGER of its two edge rays (the middle ray ranks such tiles far too low, and a long tile that
+// starts late is what a launch waits for at its end).  List scheduling of measured tile lives on the 4096 wave slots (profiles/r02_experiments.md):
+// middle ray 1.090 x the ideal, longer edge ray 1.015, the measured lives themselves 1.010.  An optional term counts the pixels of the tile's
+// window (CVX_TILE_COST_PIXELS; it helped the middle-ray estimate by 1 % and hurts this one).
+float EstimateTileCost(const cvx_context *ctx, const DevFrame &F, const DevSegment &S, int tileInSeg)
+{
+	const int first = tileInSeg * CVX_WAVE;
+	const int last = std::min(first + CVX_WAVE - 1, (S.rayCount > 0 ? S.rayCount : 1) - 1);
+	const float visits = ctx->tileCostMiddleRay ? RayColumnVisits(ctx, F, S, first + CVX_WAVE / 2)
+	                                            : std::max(RayColumnVisits(ctx, F, S, first), RayColumnVisits(ctx, F, S, last));
+	return visits + ctx->tileCostPixelWeight * (float)(S.omax - S.omin + 1);
 }
 
 // Fills SegmentContext[4] the way DrawSegments does (RenderManager.cs:281-318)
@@ -487,6 +497,7 @@ int cvx_create(int device, cvx_context **out)
 			int bx = 0, by = 0;
 			if (std::sscanf(v, "%dx%d", &bx, &by) == 2 && bx >= 1 && by >= 1 && bx * by >= 64 && bx * by <= 1024 && (bx * by) % 64 == 0) { ctx->blitBlockX = bx; ctx->blitBlockY = by; }
 		}
+		if (const char *v = std::getenv("CVX_TILE_COST_MIDDLE_RAY")) { ctx->tileCostMiddleRay = std::atoi(v) != 0; } // diagnostics: the round-1 estimate
 		if (const char *v = std::getenv("CVX_TILE_COST_PIXELS")) { // diagnostics
 			const float w = (float)std::atof(v);
 			if (w >= 0.f && w <= 100.f) { ctx->tileCostPixelWeight = w; }

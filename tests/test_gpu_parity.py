@@ -262,12 +262,14 @@ def test_sub_tile_split_is_invisible(split, monkeypatch):
         ctx.close()
 
 
-@pytest.mark.parametrize("order", ["reverse", "random", "pixels0", "pixels8"])
+@pytest.mark.parametrize("order", ["reverse", "random", "pixels8", "middle"])
 def test_launch_order_is_invisible(order, monkeypatch):
-    """The tiles of a batch are launched longest-first by an estimate (column visits + window pixels, EstimateTileCost); the estimate and
+    """The tiles of a batch are launched longest-first by an estimate (column visits of the tile's longer edge ray, EstimateTileCost); the estimate and
     the order are scheduling only -- every tile writes its own rows -- so any order gives the same raybuffers."""
     if order.startswith("pixels"):
         monkeypatch.setenv("CVX_TILE_COST_PIXELS", order[len("pixels"):])
+    elif order == "middle":
+        monkeypatch.setenv("CVX_TILE_COST_MIDDLE_RAY", "1")
     else:
         monkeypatch.setenv("CVX_TILE_ORDER", order)
     names = ["proc256_t0_lod8", "proc256_t04_lod8", "proc256_t075_lod8", "proc256_t075_lod1"]  # one world, one resolution
