@@ -56,6 +56,7 @@ def parse_args():
     ap.add_argument("--latency-frames", type=int, default=200, help="N = 1: frames of the single-frame latency legs (0 = skip)")
     ap.add_argument("--pmc-csv", default=None, help="counter summary of a rocprofv3 --pmc run of THIS command (tools/pmc_passes.sh + "
                     "tools/pmc_aggregate.py): fills roofline.traffic from FETCH_SIZE + WRITE_SIZE; without it traffic is null")
+    ap.add_argument("--comm-timeout", type=float, default=180.0, help="N > 1: seconds cvx_comm_create may wait for the peers (then exit code 4)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' = single-GPU rehearsal of the N > 1 path "
                     "(all ranks share the visible GPUs, tiles travel through host memory)")
     return ap.parse_args()
@@ -94,14 +95,33 @@ def load_world(name: str, rank: int, world_size: int, barrier):
     return ws
 
 
+def self_launch(n: int) -> int:
+    """Starts `python -m torch.distributed.run --nproc-per-node n bench.py <same arguments>` as a child process, relays its
+    output (rank 0 prints the JSON line) and returns its exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:  # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: --gpus %d without WORLD_SIZE, launching: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` as ONE process (how the driver starts it): become the launcher.  Nothing in this process has
+        # touched torch or HIP yet, and it never will -- the ranks are fresh children of torch.distributed.run, never an exec of a
+        # process that has initialised the GPU.
+        raise SystemExit(self_launch(args.gpus))
     if world_size != args.gpus:
-        if world_size == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
         args.gpus = world_size
 
     import numpy as np
@@ -110,8 +130,13 @@ def main():
 
     from cpuvox_amd import gpu, host
 
+    if world_size > 1:
+        print(f"bench.py: rank {rank} of {world_size} up (local rank {local_rank}, backend {args.backend})", file=sys.stderr, flush=True)
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+        raise SystemExit(f"bench.py (rank {rank} of {world_size}) needs a GPU: the product path has no CPU fallback")
+    if args.backend == "nccl" and world_size > torch.cuda.device_count():
+        raise SystemExit(f"bench.py --gpus {world_size}: only {torch.cuda.device_count()} GPU(s) visible; RCCL needs one device per rank "
+                         "(--backend gloo rehearses the N > 1 path on fewer devices)")
     local_rank %= torch.cuda.device_count()  # only differs from LOCAL_RANK in a --backend gloo rehearsal
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -174,33 +199,47 @@ def main():
         # The exchange behind the C ABI (cvx_shard_plan_* + cvx_exchange on a communicator the library owns); the plans above
         # stay for verification (assemble) and as the torch.distributed fallback.
         if args.backend == "nccl" and not args.torch_exchange:
+            # Every rank runs the SAME sequence of collectives whatever fails locally: (1) build + verify the native plans, (2) rank 0
+            # makes the id, (3) broadcast it, (4) all-reduce "everything fine so far", and only if that holds on every rank
+            # (5) cvx_comm_create -- so either all ranks enter ncclCommInitRank or none does -- then (6) all-reduce its outcome.
+            why = None
             try:
                 native_plans = [gpu.NativeShardPlan(pk, W, H, rank, N) for pk in packed]
                 for a, b in zip(native_plans, plans):
-                    assert a.tile_count == b.tile_count and list(a.send_start) == list(b.send_start) and list(a.disp_start) == list(b.disp_start)
-                uid = [None]
-                if rank == 0:
-                    try:
-                        uid[0] = gpu.comm_unique_id()
-                    except Exception as e:  # noqa: BLE001  (the broadcast below must still happen: the peers are waiting in it)
-                        uid[0] = f"error: {e}"
-                dist.broadcast_object_list(uid, src=0)
-                if not isinstance(uid[0], bytes):
-                    raise RuntimeError(f"rank 0 could not make a RCCL id ({uid[0]})")
-                comm = gpu.comm_create(ctx, uid[0], rank, N)
-                exchange_path = "cvx_exchange (grouped ncclSend/ncclRecv inside libcpuvox_gpu, library-owned communicator)"
+                    if not (a.tile_count == b.tile_count and list(a.send_start) == list(b.send_start) and list(a.disp_start) == list(b.disp_start)):
+                        raise RuntimeError("native shard plan differs from the Python plan")
             except Exception as e:  # noqa: BLE001
-                native_plans, comm = None, None
-                exchange_path = f"torch.distributed batch_isend_irecv (C-ABI exchange unavailable: {e})"
-            # every rank must take the same path
-            flag = torch.tensor([1 if comm else 0], dtype=torch.int32, device=device)
+                why = f"shard plan: {e}"
+            uid = [None]
+            if rank == 0:
+                try:
+                    uid[0] = gpu.comm_unique_id()
+                except Exception as e:  # noqa: BLE001
+                    uid[0] = f"error: {e}"
+            dist.broadcast_object_list(uid, src=0)
+            if why is None and not isinstance(uid[0], bytes):
+                why = f"rank 0 could not make a RCCL id ({uid[0]})"
+            flag = torch.tensor([1 if why is None else 0], dtype=torch.int32, device=device)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if not bool(flag.item()):
+            if bool(flag.item()):
+                try:
+                    comm = gpu.comm_create(ctx, uid[0], rank, N, timeout_s=args.comm_timeout)
+                except Exception as e:  # noqa: BLE001  (a timeout means a peer is gone: the all-reduce below would hang too)
+                    if "did not return within" in str(e):
+                        print(f"bench.py rank {rank}: {e}", file=sys.stderr, flush=True)
+                        os._exit(4)
+                    why = f"cvx_comm_create: {e}"
+                flag = torch.tensor([1 if comm else 0], dtype=torch.int32, device=device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            elif why is None:
+                why = "a peer could not prepare the C-ABI exchange"
+            if bool(flag.item()):
+                exchange_path = "cvx_exchange (grouped ncclSend/ncclRecv inside libcpuvox_gpu, library-owned communicator)"
+            else:
                 if comm:
                     gpu.comm_destroy(comm)
                 native_plans, comm = None, None
-                if exchange_path.startswith("cvx_exchange"):
-                    exchange_path = "torch.distributed batch_isend_irecv (a peer could not create the C-ABI communicator)"
+                exchange_path = f"torch.distributed batch_isend_irecv (C-ABI exchange unavailable: {why or 'a peer could not create the communicator'})"
         else:
             exchange_path = "torch.distributed batch_isend_irecv"
         send_rows = max(1, max(p.send_total for p in plans))
@@ -522,17 +561,33 @@ def cpu_baseline(ws, frames, W, H, budget_s: float, parity_frames=()):
     (td_rays, td_w), (lr_rays, lr_w) = O.raybuffer_shapes(W, H)
     bufs = (np.zeros((td_rays, td_w), dtype=np.uint32), np.zeros((lr_rays, lr_w), dtype=np.uint32))
     O.draw_segments(ws, frames[0], W, H, counters=False, out=bufs)  # warm-up (page in the world)
-    rays = 0
-    n = 0
-    t0 = time.perf_counter()
-    while True:  # bounded by wall time: frames differ a lot in cost
-        f = frames[n % len(frames)]
-        O.draw_segments(ws, f, W, H, counters=False, out=bufs)
-        rays += f.totalRays
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt >= budget_s or n >= 4096:
-            break
+    def sample(library, seconds):
+        r = k = 0
+        t_start = time.perf_counter()
+        while True:  # bounded by wall time: frames differ a lot in cost
+            f = frames[k % len(frames)]
+            O.draw_segments(ws, f, W, H, counters=False, out=bufs, library=library)
+            r += f.totalRays
+            k += 1
+            t = time.perf_counter() - t_start
+            if t >= seconds or k >= 4096:
+                return r, k, t
+
+    rays, n, dt = sample(None, budget_s)
+    # A second, fairer number for the reference's real build: Burst compiles these jobs with FloatMode.Fast (DrawSegmentRayJob.cs:11,
+    # 48,86,155), i.e. reassociation / contraction allowed.  Same C file, -O3 -march=native -ffast-math, same threads, same frames;
+    # never parity-checked (its pixels may legitimately differ) and never `value`.
+    fast = None
+    try:
+        fl = O.lib_fast()
+        if fl is not None:
+            O.draw_segments(ws, frames[0], W, H, counters=False, out=bufs, library=fl)
+            fr, fn, fdt = sample(fl, max(3.0, budget_s / 3))
+            fast = {"value": round(fr / fdt / 1e6, 4), "unit": "Mrays/s", "fps": round(fn / fdt, 2), "cores": threads, "parity_checked": False,
+                    "build": "gcc -O3 -march=native -ffast-math (Burst FloatMode.Fast analogue), built on this host",
+                    "sample": f"{fn} frames ({fr} rays), {fdt:.1f} s wall"}
+    except Exception as e:  # noqa: BLE001
+        fast = {"value": None, "error": str(e)}
     baseline = {
         "value": round(rays / dt / 1e6, 4),
         "unit": "Mrays/s",
@@ -540,6 +595,8 @@ def cpu_baseline(ws, frames, W, H, budget_s: float, parity_frames=()):
         "kind": "port",
         "fps": round(n / dt, 2),
         "sample": f"{n} frames cycling over the first timed step ({rays} rays), {dt:.1f} s wall, OpenMP {threads} threads, wall clock of orc_draw_segments only",
+        "build": "gcc -O2 -ffp-contract=off -fno-fast-math (strict IEEE: the parity contract)",
+        "fast_math": fast,
     }
     from cpuvox_amd import dist as cdist
 

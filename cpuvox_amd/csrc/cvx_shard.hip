@@ -7,10 +7,15 @@
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
+#include <rccl/rccl.h>
 
 #include <cmath>
+#include <chrono>
 #include <cstring>
+#include <future>
+#include <memory>
 #include <mutex>
+#include <thread>
 #include <new>
 #include <vector>
 
@@ -43,23 +48,27 @@ int RoundClamp(float v, int lo, int hi)
 }
 
 // ---- RCCL, resolved at run time -------------------------------------------------------------------------------------
-struct NcclUniqueId {
-	char internal[128];
-};
-typedef int (*FnGetUniqueId)(NcclUniqueId *);
-typedef int (*FnCommInitRank)(void **, int, NcclUniqueId, int);
-typedef int (*FnCommDestroy)(void *);
-typedef int (*FnGroup)(void);
-typedef int (*FnSendRecv)(void *, size_t, int /*ncclDataType_t*/, int, void *, hipStream_t);
-typedef const char *(*FnGetErrorString)(int);
+// librccl is dlopen()ed on first use (a single-GPU host needs none); the function-pointer types come from RCCL's own header,
+// so a prototype that drifts from the installed library is a compile error, not a silent ABI mismatch.
+typedef decltype(&ncclGetUniqueId) FnGetUniqueId;
+typedef decltype(&ncclCommInitRank) FnCommInitRank;
+typedef decltype(&ncclCommDestroy) FnCommDestroy;
+typedef decltype(&ncclCommAbort) FnCommAbort;
+typedef decltype(&ncclGroupStart) FnGroup;
+typedef decltype(&ncclSend) FnSend;
+typedef decltype(&ncclRecv) FnRecv;
+typedef decltype(&ncclGetErrorString) FnGetErrorString;
+static_assert(sizeof(ncclUniqueId) == 128, "cvx_comm_unique_id hands out 128 bytes");
 
 struct Rccl {
 	void *handle = nullptr;
 	FnGetUniqueId getUniqueId = nullptr;
 	FnCommInitRank commInitRank = nullptr;
 	FnCommDestroy commDestroy = nullptr;
+	FnCommAbort commAbort = nullptr;
 	FnGroup groupStart = nullptr, groupEnd = nullptr;
-	FnSendRecv send = nullptr, recv = nullptr;
+	FnSend send = nullptr;
+	FnRecv recv = nullptr;
 	FnGetErrorString errorString = nullptr;
 	bool ok = false;
 };
@@ -77,19 +86,18 @@ Rccl &LoadRccl()
 		r.getUniqueId = (FnGetUniqueId)dlsym(r.handle, "ncclGetUniqueId");
 		r.commInitRank = (FnCommInitRank)dlsym(r.handle, "ncclCommInitRank");
 		r.commDestroy = (FnCommDestroy)dlsym(r.handle, "ncclCommDestroy");
+		r.commAbort = (FnCommAbort)dlsym(r.handle, "ncclCommAbort");
 		r.groupStart = (FnGroup)dlsym(r.handle, "ncclGroupStart");
 		r.groupEnd = (FnGroup)dlsym(r.handle, "ncclGroupEnd");
-		r.send = (FnSendRecv)dlsym(r.handle, "ncclSend");
-		r.recv = (FnSendRecv)dlsym(r.handle, "ncclRecv");
+		r.send = (FnSend)dlsym(r.handle, "ncclSend");
+		r.recv = (FnRecv)dlsym(r.handle, "ncclRecv");
 		r.errorString = (FnGetErrorString)dlsym(r.handle, "ncclGetErrorString");
 		r.ok = r.getUniqueId && r.commInitRank && r.commDestroy && r.groupStart && r.groupEnd && r.send && r.recv;
 	});
 	return r;
 }
 
-const int kNcclInt8 = 0; // ncclInt8 / ncclChar (rccl.h: ncclDataType_t)
-
-int NcclFail(cvx_context *ctx, Rccl &r, const char *what, int rc)
+int NcclFail(cvx_context *ctx, Rccl &r, const char *what, ncclResult_t rc)
 {
 	return Fail(ctx, CVX_ERR_HIP, "%s failed: %s", what, r.errorString ? r.errorString(rc) : "RCCL error");
 }
@@ -106,8 +114,10 @@ int cvx_shard_plan_create(int frameCount, const cvx_segment_data *segments, cons
 	if (frameCount <= 0 || !segments || !vanishingPoints || screenWidth <= 0 || screenHeight <= 0 || worldSize < 1 || rank < 0 || rank >= worldSize) {
 		return Fail(nullptr, CVX_ERR_INVALID_ARGUMENT, "bad shard plan arguments");
 	}
-	cvx_shard_plan *p = new (std::nothrow) cvx_shard_plan();
+	// (the vectors below grow: nothing may escape across the C boundary, and a half-built plan is not leaked)
+	std::unique_ptr<cvx_shard_plan> p(new (std::nothrow) cvx_shard_plan());
 	if (!p) { return Fail(nullptr, CVX_ERR_HIP, "out of host memory"); }
+	try {
 	const int N = worldSize, W = screenWidth, H = screenHeight;
 	p->rank = rank;
 	p->worldSize = N;
@@ -144,7 +154,10 @@ int cvx_shard_plan_create(int frameCount, const cvx_segment_data *segments, cons
 		p->sendStart[(size_t)i + 1] = p->sendStart[(size_t)i] + sendRows[(size_t)i];
 		p->dispStart[(size_t)i + 1] = p->dispStart[(size_t)i] + dispRows[(size_t)i];
 	}
-	*out = p;
+	} catch (const std::exception &e) {
+		return Fail(nullptr, CVX_ERR_HIP, "cvx_shard_plan_create: %s", e.what());
+	}
+	*out = p.release();
 	return CVX_OK;
 }
 
@@ -189,26 +202,55 @@ int cvx_comm_unique_id(void *id128)
 	if (!id128) { return Fail(nullptr, CVX_ERR_INVALID_ARGUMENT, "id128 is NULL"); }
 	Rccl &r = LoadRccl();
 	if (!r.ok) { return Fail(nullptr, CVX_ERR_NOT_READY, "librccl could not be loaded"); }
-	NcclUniqueId id;
-	const int rc = r.getUniqueId(&id);
-	if (rc != 0) { return NcclFail(nullptr, r, "ncclGetUniqueId", rc); }
+	ncclUniqueId id;
+	const ncclResult_t rc = r.getUniqueId(&id);
+	if (rc != ncclSuccess) { return NcclFail(nullptr, r, "ncclGetUniqueId", rc); }
 	std::memcpy(id128, &id, sizeof id);
+	return CVX_OK;
+}
+
+// ncclCommInitRank blocks until every rank of the clique has arrived; a peer that never comes (crashed, wrong id, no route)
+// would leave the caller hanging for as long as its job scheduler allows.  The call therefore runs on a helper thread and
+// is given up after `timeoutSeconds`: the caller gets CVX_ERR_TIMEOUT and is expected to end the process (the helper thread
+// stays parked inside RCCL; there is no portable way to cancel it).
+int cvx_comm_create_timeout(cvx_context *ctx, const void *id128, int rank, int worldSize, double timeoutSeconds, void **comm)
+{
+	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
+	if (!id128 || !comm || worldSize < 1 || rank < 0 || rank >= worldSize || !(timeoutSeconds > 0.0)) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "bad communicator arguments"); }
+	*comm = nullptr;
+	Rccl &r = LoadRccl();
+	if (!r.ok) { return Fail(ctx, CVX_ERR_NOT_READY, "librccl could not be loaded"); }
+	struct Job {
+		ncclUniqueId id;
+		ncclComm_t comm = nullptr;
+		std::promise<ncclResult_t> done;
+	};
+	auto job = std::make_shared<Job>();
+	std::memcpy(&job->id, id128, sizeof job->id);
+	std::future<ncclResult_t> fut = job->done.get_future();
+	const int device = ctx->device;
+	const FnCommInitRank init = r.commInitRank;
+	try {
+		std::thread([job, init, device, rank, worldSize] {
+			ncclResult_t rc = ncclUnhandledCudaError;
+			if (hipSetDevice(device) == hipSuccess) { rc = init(&job->comm, worldSize, job->id, rank); }
+			job->done.set_value(rc);
+		}).detach();
+	} catch (const std::exception &e) {
+		return Fail(ctx, CVX_ERR_HIP, "cvx_comm_create: %s", e.what());
+	}
+	if (fut.wait_for(std::chrono::duration<double>(timeoutSeconds)) != std::future_status::ready) {
+		return Fail(ctx, CVX_ERR_TIMEOUT, "ncclCommInitRank(rank %d of %d) did not return within %.0f s: a peer is missing or unreachable", rank, worldSize, timeoutSeconds);
+	}
+	const ncclResult_t rc = fut.get();
+	if (rc != ncclSuccess) { return NcclFail(ctx, r, "ncclCommInitRank", rc); }
+	*comm = job->comm;
 	return CVX_OK;
 }
 
 int cvx_comm_create(cvx_context *ctx, const void *id128, int rank, int worldSize, void **comm)
 {
-	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
-	if (!id128 || !comm || worldSize < 1 || rank < 0 || rank >= worldSize) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "bad communicator arguments"); }
-	*comm = nullptr;
-	Rccl &r = LoadRccl();
-	if (!r.ok) { return Fail(ctx, CVX_ERR_NOT_READY, "librccl could not be loaded"); }
-	CVX_HIP(ctx, hipSetDevice(ctx->device));
-	NcclUniqueId id;
-	std::memcpy(&id, id128, sizeof id);
-	const int rc = r.commInitRank(comm, worldSize, id, rank);
-	if (rc != 0) { return NcclFail(ctx, r, "ncclCommInitRank", rc); }
-	return CVX_OK;
+	return cvx_comm_create_timeout(ctx, id128, rank, worldSize, 180.0, comm);
 }
 
 int cvx_comm_destroy(void *comm)
@@ -216,7 +258,7 @@ int cvx_comm_destroy(void *comm)
 	if (!comm) { return CVX_OK; }
 	Rccl &r = LoadRccl();
 	if (!r.ok) { return CVX_ERR_NOT_READY; }
-	return r.commDestroy(comm) == 0 ? CVX_OK : CVX_ERR_HIP;
+	return r.commDestroy((ncclComm_t)comm) == ncclSuccess ? CVX_OK : CVX_ERR_HIP;
 }
 
 int cvx_exchange(cvx_context *ctx, const cvx_shard_plan *plan, void *comm, void *hipStream, void *sendBase, void *dispBase)
@@ -233,17 +275,18 @@ int cvx_exchange(cvx_context *ctx, const cvx_shard_plan *plan, void *comm, void 
 	const size_t rowBytes = CVX_WAVE * 4;
 	// One ncclSend + one ncclRecv per peer, grouped: every pair rides its own xGMI link, no ring; the received rows land in
 	// the display area exactly where the blit / read-back expects them (the peer's send section for me has my layout).
-	int rc = r.groupStart();
-	if (rc != 0) { return NcclFail(ctx, r, "ncclGroupStart", rc); }
-	for (int peer = 0; peer < N && rc == 0; peer++) {
+	ncclResult_t rc = r.groupStart();
+	if (rc != ncclSuccess) { return NcclFail(ctx, r, "ncclGroupStart", rc); }
+	const ncclComm_t c = (ncclComm_t)comm;
+	for (int peer = 0; peer < N && rc == ncclSuccess; peer++) {
 		int64_t s0, sn, r0, rn;
 		(void)cvx_shard_plan_transfer(plan, peer, &s0, &sn, &r0, &rn); // (0 rows for peer == rank)
-		if (sn > 0) { rc = r.send(static_cast<uint8_t *>(sendBase) + (size_t)s0 * rowBytes, (size_t)sn * rowBytes, kNcclInt8, peer, comm, st); }
-		if (rc == 0 && rn > 0) { rc = r.recv(static_cast<uint8_t *>(dispBase) + (size_t)r0 * rowBytes, (size_t)rn * rowBytes, kNcclInt8, peer, comm, st); }
+		if (sn > 0) { rc = r.send(static_cast<uint8_t *>(sendBase) + (size_t)s0 * rowBytes, (size_t)sn * rowBytes, ncclInt8, peer, c, st); }
+		if (rc == ncclSuccess && rn > 0) { rc = r.recv(static_cast<uint8_t *>(dispBase) + (size_t)r0 * rowBytes, (size_t)rn * rowBytes, ncclInt8, peer, c, st); }
 	}
-	const int rcEnd = r.groupEnd();
-	if (rc != 0) { return NcclFail(ctx, r, "ncclSend / ncclRecv", rc); }
-	if (rcEnd != 0) { return NcclFail(ctx, r, "ncclGroupEnd", rcEnd); }
+	const ncclResult_t rcEnd = r.groupEnd();
+	if (rc != ncclSuccess) { return NcclFail(ctx, r, "ncclSend / ncclRecv", rc); }
+	if (rcEnd != ncclSuccess) { return NcclFail(ctx, r, "ncclGroupEnd", rcEnd); }
 	return CVX_OK;
 }
 

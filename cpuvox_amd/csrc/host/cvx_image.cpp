@@ -358,8 +358,12 @@ bool DecodeJpeg(const std::vector<uint8_t> &file, Image &out, std::string *error
 		if (marker == 0xD9) { break; }
 		const int length = be16(pos + 2);
 		if (length < 2 || pos + 2 + (size_t)length > n) { return Fail(error, "truncated JPEG segment"); }
-		const uint8_t *seg = &file[pos + 4];
+		const uint8_t *seg = file.data() + pos + 4; // (may be one past the end for an empty segment: never dereferenced then)
 		const int segLen = length - 2;
+		if (marker == 0xEE && segLen >= 12 && std::memcmp(seg, "Adobe", 5) == 0 && seg[11] != 1) {
+			// APP14: transform 0 = RGB (or CMYK), 2 = YCCK.  Only JFIF-style YCbCr / grey is decoded; wrong colours without an error are worse than a refusal.
+			return Fail(error, "unsupported JPEG colour transform (Adobe APP14: not YCbCr)");
+		}
 		if (marker == 0xDB) { // DQT
 			int i = 0;
 			while (i < segLen) {
@@ -443,7 +447,7 @@ bool DecodeJpeg(const std::vector<uint8_t> &file, Image &out, std::string *error
 				if ((!progressive || ss > 0) && !acTables[c->ta].defined && !(progressive && ss == 0)) { return Fail(error, "JPEG scan uses an undefined AC table"); }
 				c->dcPred = 0;
 			}
-			JpegBits bits{ &file[pos + 2 + (size_t)length], file.data() + n };
+			JpegBits bits{ file.data() + pos + 2 + (size_t)length, file.data() + n };
 			int eobrun = 0;
 			// one block of a scan; returns false on a corrupt code
 			auto decodeBlock = [&](JpegComponent &c, int16_t *blk) -> bool {
@@ -451,6 +455,7 @@ bool DecodeJpeg(const std::vector<uint8_t> &file, Image &out, std::string *error
 					const int t = bits.Decode(dcTables[c.td]);
 					if (t < 0 || t > 11) { return false; }
 					c.dcPred += JpegBits::Extend(bits.Receive(t), t);
+					if (c.dcPred < -32768 || c.dcPred > 32767) { return false; } // (a crafted stream must not run the predictor into signed overflow)
 					blk[0] = (int16_t)c.dcPred;
 					for (int k = 1; k < 64;) {
 						const int rs = bits.Decode(acTables[c.ta]);
@@ -473,6 +478,7 @@ bool DecodeJpeg(const std::vector<uint8_t> &file, Image &out, std::string *error
 						const int t = bits.Decode(dcTables[c.td]);
 						if (t < 0 || t > 11) { return false; }
 						c.dcPred += JpegBits::Extend(bits.Receive(t), t);
+						if (c.dcPred < -32768 || c.dcPred > 32767) { return false; }
 						blk[0] = (int16_t)(c.dcPred * (1 << al));
 					} else if (bits.Bit()) {
 						blk[0] = (int16_t)(blk[0] | (1 << al));

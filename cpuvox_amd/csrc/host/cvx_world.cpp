@@ -195,8 +195,11 @@ bool World::ValidateBlob(int3 dims, int lod, const void *data, int64_t byteLengt
 			total += e.Length;
 			if (e.ColorsIndex >= 0 && (int64_t)e.ColorsIndex + e.Length > colours) { colours = (int64_t)e.ColorsIndex + e.Length; }
 		}
-		if (total > maxY || off + c.runCount + 2 + colours > elementCount) {
-			return fail("LOD " + std::to_string(lod) + " column " + std::to_string(i) + ": runs exceed the world height or colours exceed the pool");
+		// total == height, the rule cvx_world_upload enforces as well (RLEColumnBuilder.ToFinalColumn always emits full-height columns,
+		// WordBuilder.cs:232-258; the device walks ONE run table in both directions, which needs it): a blob this library loads is a
+		// blob the GPU library accepts.
+		if (total != maxY || off + c.runCount + 2 + colours > elementCount) {
+			return fail("LOD " + std::to_string(lod) + " column " + std::to_string(i) + ": runs do not add up to the column height or colours exceed the pool");
 		}
 	}
 	return true;

@@ -31,7 +31,7 @@ EXPORTS = [
     "cvx_get_raybuffer_layout", "cvx_selftest_math", "cvx_version", "cvx_bind_raybuffers", "cvx_draw_time_stats", "cvx_debug_section_cycles", "cvx_debug_occupancy", "cvx_copy_rows", "cvx_draw_segments_placed",
     "cvx_world_downsample", "cvx_world_build_lods", "cvx_free", "cvx_debug_section_histogram",
     "cvx_shard_plan_create", "cvx_shard_plan_destroy", "cvx_shard_plan_tile_count", "cvx_shard_plan_sections", "cvx_shard_plan_tile_out", "cvx_shard_plan_transfer",
-    "cvx_comm_unique_id", "cvx_comm_create", "cvx_comm_destroy", "cvx_exchange",
+    "cvx_comm_unique_id", "cvx_comm_create", "cvx_comm_create_timeout", "cvx_comm_destroy", "cvx_exchange",
 ]
 
 
@@ -132,6 +132,7 @@ def lib() -> C.CDLL:
         L.cvx_shard_plan_transfer.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.cvx_comm_unique_id.argtypes = [C.c_void_p]
         L.cvx_comm_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.cvx_comm_create_timeout.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_void_p)]
         L.cvx_comm_destroy.argtypes = [C.c_void_p]
         L.cvx_exchange.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
@@ -426,9 +427,10 @@ def comm_unique_id() -> bytes:
     return buf.raw
 
 
-def comm_create(ctx: Context, unique_id: bytes, rank: int, world_size: int) -> int:
+def comm_create(ctx: Context, unique_id: bytes, rank: int, world_size: int, timeout_s: float = 180.0) -> int:
+    """ncclCommInitRank through the C ABI; raises (CVX_ERR_TIMEOUT) when the clique is not complete after `timeout_s`."""
     comm = C.c_void_p()
-    ctx._check(lib().cvx_comm_create(ctx._h, unique_id, rank, world_size, C.byref(comm)))
+    ctx._check(lib().cvx_comm_create_timeout(ctx._h, unique_id, rank, world_size, float(timeout_s), C.byref(comm)))
     return comm.value
 
 

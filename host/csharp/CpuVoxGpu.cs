@@ -107,6 +107,7 @@ namespace CpuVox.Gpu
 		[DllImport(Lib)] public static extern int cvx_shard_plan_tile_out(IntPtr plan, void* sendBase, void* dispBase, ulong* tileOut);
 		[DllImport(Lib)] public static extern int cvx_comm_unique_id(void* id128);
 		[DllImport(Lib)] public static extern int cvx_comm_create(IntPtr ctx, void* id128, int rank, int worldSize, out IntPtr comm);
+		[DllImport(Lib)] public static extern int cvx_comm_create_timeout(IntPtr ctx, void* id128, int rank, int worldSize, double timeoutSeconds, out IntPtr comm);
 		[DllImport(Lib)] public static extern int cvx_comm_destroy(IntPtr comm);
 		[DllImport(Lib)] public static extern int cvx_exchange(IntPtr ctx, IntPtr plan, IntPtr comm, IntPtr hipStream, void* sendBase, void* dispBase);
 	}

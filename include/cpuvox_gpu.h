@@ -35,6 +35,7 @@ enum {
 	CVX_ERR_HIP = -2,          /* a HIP runtime call failed (no device, OOM, ...) */
 	CVX_ERR_NOT_READY = -3,    /* world / resolution not set */
 	CVX_ERR_CAPACITY = -4,     /* ray count exceeds the raybuffer capacity */
+	CVX_ERR_TIMEOUT = -5,      /* a peer did not arrive in time (cvx_comm_create) */
 };
 
 enum {
@@ -178,6 +179,9 @@ int cvx_shard_plan_tile_out(const cvx_shard_plan *plan, void *sendBase, void *di
  * the other ranks over its own channel, every rank calls cvx_comm_create.  A communicator made elsewhere (ncclComm_t) works too. */
 int cvx_comm_unique_id(void *id128);
 int cvx_comm_create(cvx_context *ctx, const void *id128, int rank, int worldSize, void **comm);
+/* ... with an explicit limit on how long to wait for the peers (cvx_comm_create waits 180 s): CVX_ERR_TIMEOUT when a rank of
+ * the clique never arrives -- the sharded `render.Complete()` (RenderManager.cs:363) must not hang for ever on a dead peer. */
+int cvx_comm_create_timeout(cvx_context *ctx, const void *id128, int rank, int worldSize, double timeoutSeconds, void **comm);
 int cvx_comm_destroy(void *comm);
 /* The exchange of one batch on hipStream (NULL = the context's stream): returns after enqueueing; order the consumer with the stream. */
 int cvx_exchange(cvx_context *ctx, const cvx_shard_plan *plan, void *comm, void *hipStream, void *sendBase, void *dispBase);

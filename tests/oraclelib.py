@@ -74,6 +74,35 @@ def lib() -> C.CDLL:
     return _lib
 
 
+_lib_fast = None
+
+
+def lib_fast():
+    """The same C file built the way Burst builds the reference's jobs (FloatMode.Fast, DrawSegmentRayJob.cs:11,48,86,155):
+    -O3 -march=native -ffast-math, FMA contraction allowed.  NOT a parity build -- its pixels may differ from the strict
+    port's, and it is only ever timed (bench.py cpu_baseline.fast_math).  Compiled on the machine it runs on (-march=native)
+    into a private temporary directory; None when no compiler is available."""
+    global _lib_fast
+    if _lib_fast is None:
+        import tempfile
+
+        out_dir = tempfile.mkdtemp(prefix="cvx_oracle_fast_")
+        path = os.path.join(out_dir, "libcvx_oracle_fast.so")
+        cmd = [os.environ.get("CC", "gcc"), "-std=c11", "-O3", "-march=native", "-ffast-math", "-fopenmp", "-fPIC", "-shared", "-o", path,
+               os.path.join(ORACLE_DIR, "cvx_oracle.c"), "-lm"]
+        try:
+            subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        except (OSError, subprocess.CalledProcessError):
+            _lib_fast = False
+            return None
+        L = C.CDLL(path)
+        L.orc_draw_segments.restype = C.c_int
+        L.orc_draw_segments.argtypes = lib().orc_draw_segments.argtypes
+        L.orc_max_threads.restype = C.c_int
+        _lib_fast = L
+    return _lib_fast or None
+
+
 def orc_worlds(world_set):
     """orc_world[6] describing a cpuvox_amd.host.WorldSet (no copies)."""
     arr = (OrcWorld * LOD_LEVELS)()
@@ -91,7 +120,7 @@ def raybuffer_shapes(width: int, height: int):
     return (width + 2 * height, height), (2 * width + height, width)
 
 
-def draw_segments(world_set, frame, width: int, height: int, threads: int = 0, clear: int = 0, counters: bool = True, out=None):
+def draw_segments(world_set, frame, width: int, height: int, threads: int = 0, clear: int = 0, counters: bool = True, out=None, library=None):
     """Run the oracle's DrawSegments on a cpuvox_amd.host.Frame.
 
     Returns (topDown[rays, H] uint32, leftRight[rays, W] uint32, OrcCounters).
@@ -107,7 +136,7 @@ def draw_segments(world_set, frame, width: int, height: int, threads: int = 0, c
     worlds = orc_worlds(world_set)
     cnt = OrcCounters()
     vp = (C.c_float * 2)(*frame.vanishingPointScreenSpace)
-    rc = lib().orc_draw_segments(C.addressof(frame.segments), C.addressof(worlds), C.addressof(frame.camera), width, height,
+    rc = (library or lib()).orc_draw_segments(C.addressof(frame.segments), C.addressof(worlds), C.addressof(frame.camera), width, height,
                                  C.addressof(vp), td.ctypes.data, lr.ctypes.data, threads,
                                  C.addressof(cnt) if counters else None)
     if rc < 0:

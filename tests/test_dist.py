@@ -22,6 +22,7 @@ import oraclelib as O
 import scenes
 from cpuvox_amd import dist as cdist
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 W, H = 320, 200
 TIMES = (0.1, 0.5, 0.75, 0.9, 1.1)
 
@@ -183,3 +184,22 @@ def test_zero_copy_shard_plan_world_size_2_gloo():
         assert p.exitcode == 0
     assert all(ok for _, ok, _, _ in results), results
     assert results[0][2] > 0 and results[1][2] > 0
+
+
+def test_bench_self_launches_one_process_per_gpu():
+    """`python bench.py --gpus 2` started as ONE process (the driver's command) must become a torch.distributed.run launcher:
+    two ranks come up (here they stop at "needs a GPU"), nothing dies in argument handling, the exit code is the children's."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1", "--warmup", "0"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert "launching:" in r.stderr and "--nproc-per-node=2" in r.stderr
+    assert "rank 0 of 2 up" in r.stderr and "rank 1 of 2 up" in r.stderr, r.stderr[-2000:]
+    import torch
+
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and "needs a GPU" in r.stderr

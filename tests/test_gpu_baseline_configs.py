@@ -46,6 +46,15 @@ def _compare(name, fr, g_td, g_lr, o_td, o_lr):
         assert (g[n:] == CLEAR).all(), f"{name}/{label}: rows beyond the used rays were written"
 
 
+def _render_build_matches(ctx, name, fr, o_td, o_lr):
+    """The SHIPPED kernel (render_kernel<false>, counters off: it leaves a finished ray once per column and takes the
+    automatic LDS-budget / sub-tile path) drawn into the same buffer again and compared with the same oracle output."""
+    ctx.enable_counters(False)
+    ctx.clear_raybuffers(0, CLEAR)
+    ctx.draw_segments(fr, 0)
+    _compare(name + " [rendering build]", fr, ctx.read_raybuffer(0, 0), ctx.read_raybuffer(0, 1), o_td, o_lr)
+
+
 def _same_counters(name, gc, oc):
     assert (gc.S, gc.E, gc.C, gc.P, gc.R) == (oc.S, oc.E, oc.C, oc.P, oc.R), (name, gc.as_dict(), oc.as_dict())
     assert list(gc.lodVisits) == list(oc.lodVisits), (name, list(gc.lodVisits), list(oc.lodVisits))
@@ -78,6 +87,7 @@ def test_config3_single_draws(proc2048):
         o_td, o_lr, oc = O.draw_segments(ws, fr, W, H, clear=CLEAR)
         _compare(f"config3 pose {index}", fr, ctx.read_raybuffer(0, 0), ctx.read_raybuffer(0, 1), o_td, o_lr)
         _same_counters(f"config3 pose {index}", gc, oc)
+        _render_build_matches(ctx, f"config3 pose {index}", fr, o_td, o_lr)
         seen_lods += np.array(list(oc.lodVisits))
     assert directions == {0, 1}, "both element iteration directions must occur"
     assert (seen_lods[:3] > 0).all() and (seen_lods[3:] == 0).all(), seen_lods
@@ -97,14 +107,23 @@ def test_config3_one_64_frame_batch(proc2048):
     ctx.draw_segments_batch(frames, 0)
     gc = ctx.counters()
     total = O.OrcCounters()
+    oracle_out = []
     for b, fr in enumerate(frames):
         o_td, o_lr, oc = O.draw_segments(ws, fr, W, H, clear=CLEAR)
+        oracle_out.append((o_td, o_lr))
         _compare(f"config3 batch frame {b} (pose {indices[b]})", fr, ctx.read_raybuffer(b, 0), ctx.read_raybuffer(b, 1), o_td, o_lr)
         for k in ("S", "E", "C", "P", "R"):
             setattr(total, k, getattr(total, k) + getattr(oc, k))
         for l in range(6):
             total.lodVisits[l] += oc.lodVisits[l]
     _same_counters("config3 batch", gc, total)
+    # ... and the same launch by the shipped kernel (counters off)
+    ctx.enable_counters(False)
+    for b in range(64):
+        ctx.clear_raybuffers(b, CLEAR)
+    ctx.draw_segments_batch(frames, 0)
+    for b, fr in enumerate(frames):
+        _compare(f"config3 batch frame {b} [rendering build]", fr, ctx.read_raybuffer(b, 0), ctx.read_raybuffer(b, 1), *oracle_out[b])
 
 
 def test_config4_4k_vp_on_screen(proc2048):
@@ -122,6 +141,7 @@ def test_config4_4k_vp_on_screen(proc2048):
         o_td, o_lr, oc = O.draw_segments(ws, fr, W, H, clear=CLEAR)
         _compare(f"config4 pose {index}", fr, ctx.read_raybuffer(0, 0), ctx.read_raybuffer(0, 1), o_td, o_lr)
         _same_counters(f"config4 pose {index}", gc, oc)
+        _render_build_matches(ctx, f"config4 pose {index}", fr, o_td, o_lr)
 
 
 def test_config5_4096_cubed_horizontal_deep_lods():
@@ -149,6 +169,7 @@ def test_config5_4096_cubed_horizontal_deep_lods():
             o_td, o_lr, oc = O.draw_segments(ws, fr, W, H, clear=CLEAR)
             _compare(f"config5 pose {i}", fr, ctx.read_raybuffer(0, 0), ctx.read_raybuffer(0, 1), o_td, o_lr)
             _same_counters(f"config5 pose {i}", gc, oc)
+            _render_build_matches(ctx, f"config5 pose {i}", fr, o_td, o_lr)
             seen += np.array(list(oc.lodVisits))
         assert (seen[:5] > 0).all(), f"LOD 0..4 must be visited: {seen}"
     finally:

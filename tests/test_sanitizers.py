@@ -99,6 +99,42 @@ def test_host_library_under_asan_and_ubsan(tmp_path):
             raise SystemExit("file with an out-of-range column accepted")
         except RuntimeError:
             pass
+        # the JPEG decoder (map_Kd textures) on untrusted bytes: truncated, bit-flipped and progressive streams, an Adobe RGB marker
+        try:
+            from PIL import Image
+        except ImportError:
+            Image = None
+        if Image is not None:
+            rng = np.random.default_rng(11)
+            img = Image.fromarray(rng.integers(0, 255, (37, 53, 3), dtype=np.uint8))
+            jpg = {str(tmp_path / "t.jpg")!r}
+            for opts in (dict(quality=90, subsampling=2), dict(quality=85, subsampling=0, progressive=True)):
+                img.save(jpg, "JPEG", **opts)
+                good = bytearray(open(jpg, "rb").read())
+                assert host.load_image(jpg).shape == (37, 53, 4)
+                cases = [good[:cut] for cut in (2, 4, 20, len(good) // 3, len(good) // 2, len(good) - 2)]
+                for k in range(60):
+                    b = bytearray(good)
+                    for _ in range(1 + k % 4):
+                        b[int(rng.integers(2, len(b)))] ^= 1 << int(rng.integers(0, 8))
+                    cases.append(b)
+                sos = good.find(b"\\xff\\xda")
+                cases.append(good[:sos + 4])                      # the file ends inside the SOS header
+                for b in cases:
+                    open(jpg, "wb").write(b)
+                    try:
+                        host.load_image(jpg)                          # either an image or a clean refusal; never a sanitizer report
+                    except RuntimeError:
+                        pass
+            img.save(jpg, "JPEG", quality=90)
+            good = bytearray(open(jpg, "rb").read())
+            app14 = b"\\xff\\xee\\x00\\x0eAdobe\\x00\\x64\\x00\\x00\\x00\\x00\\x00"    # transform 0 = RGB: refused, not decoded with wrong colours
+            open(jpg, "wb").write(good[:2] + app14 + good[2:])
+            try:
+                host.load_image(jpg)
+                raise SystemExit("Adobe RGB JPEG accepted")
+            except RuntimeError as e:
+                assert "colour transform" in str(e), e
         print("RESULT ok")
     """
     stdout = _run(code, {"CVX_HOST_LIB": os.path.join(ROOT, "cpuvox_amd", "libcpuvox_host_asan.so")})
