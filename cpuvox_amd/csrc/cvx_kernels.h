@@ -511,7 +511,8 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 	// already stands on the NEXT column, whose 32-byte record is in flight while this one is processed.
 	uint4 header, queue;              // record of the current column: header + its first two solid runs in walk order
 	float curDistLast, curDistNext;   // ray.IntersectionDistances of the current column
-	int curScale;                     // voxelScale of the current column
+	int curScale;                     // voxelScale of the current column (counting build)
+	int curShift;                     // its log2 = the LOD of the current column
 	uint32_t curElementsOff;          // element pool of the current column's LOD (colours): byte offset in the arena
 	uint32_t curRunsOff;              // run list (solid runs 2..) of the current column's LOD
 	unsigned int consumed = 0u;       // counting variant: elements the reference's walk has dereferenced in this column
@@ -618,17 +619,79 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		int solidIndex = 0;
 		const uint32_t worldColumnColorsOff = curElementsOff + header.x * 4u; // ColorPointer, World.cs:185
 
+		// Rendering build: which solid runs the walk below would project is decided without walking.  A run is projected iff it is
+		// neither entirely above worldBoundsMax (:461-467) nor entirely below worldBoundsMin (:468-475) -- the reference's early
+		// `break`s only skip runs that these two tests would skip anyway (the runs of a column are sorted by height), and the
+		// world bounds do not change inside the element loop.  So the two runs the record holds are tested here, straight-line,
+		// and the loop below just takes the visible ones in walk order; runs beyond the record (3-8 % of the columns) are
+		// scanned when their turn comes.  Same runs, same order per lane as the walk of the counting build (and the oracle).
+		bool vis0 = false, vis1 = false;
+		int ovNext = 0; // next run beyond the record to look at: 2, 3, ... (top-down walk) or solidCount - 1, ... 2 (bottom-up walk)
+		// world-space span of a run word {start | length << 16}: [top - length, top] in LOD-0 voxels (integers, see the walk below)
+		auto runSpan = [&](uint32_t w0, float &bottom, float &top) {
+			const int t = worldMaxYInt - (int)((w0 & 0xFFFFu) << curShift);
+			top = (float)t;
+			bottom = (float)(t - (int)((w0 >> 16) << curShift));
+		};
+		if (!COUNT) {
+			float b0, t0, b1, t1;
+			runSpan(queue.x, b0, t0);
+			runSpan(queue.z, b1, t1);
+			vis0 = !(b0 > worldBoundsMax) && !(t0 < worldBoundsMin); // (a column that is drawn has at least one solid run)
+			vis1 = solidCount > 1 && !(b1 > worldBoundsMax) && !(t1 < worldBoundsMin);
+			ovNext = DIR > 0 ? 2 : solidCount - 1;
+		}
+		bool ovPending = !COUNT && solidCount > 2; // runs beyond the record still to be looked at
+
 		// Element loop :441-611, realigned for SIMT: every lane first walks its own elements (cheap: decode,
 		// bounds bookkeeping, air / world-bounds culls :445-475) up to its next run that has to be projected;
 		// the expensive projection + pixel code below then runs once for all lanes that found one, instead of
 		// once per element index with whatever lanes happen to hold a solid run at that index.  The sequence of
 		// elements each lane consumes is unchanged.
-		while (true) {
+		// (rendering build: a lane stays in the loop exactly as long as it has a visible run left -- no trailing "nothing found" pass)
+		while (COUNT || vis0 || vis1 || CVX_RARE(ovPending)) {
 			int elementColorsIndex = 0, elementLength = 0;
 			bool found = false;
 			CVX_BEGIN();
 			CVX_WAITPROBE(10);
-			while (solidIndex < solidCount) {
+			if (!COUNT) {
+				// runs beyond the record: rare, so the scan sits behind one branch (bottom-up they come first, top-down last)
+				auto scanOverflow = [&]() {
+					while (DIR > 0 ? ovNext < solidCount : ovNext >= 2) {
+						const uint2 run = ld2(arena, columnRunsOff + (uint32_t)(ovNext - 2) * 8u);
+						ovNext += DIR > 0 ? 1 : -1;
+						runSpan(run.x, elementBoundsMin, elementBoundsMax);
+						if (!(elementBoundsMin > worldBoundsMax) && !(elementBoundsMax < worldBoundsMin)) {
+							elementLength = (int)(run.x >> 16);
+							elementColorsIndex = (int)(run.y & 0xFFFFu);
+							found = true;
+							break;
+						}
+					}
+					ovPending = DIR > 0 ? ovNext < solidCount : ovNext >= 2;
+				};
+				if (DIR < 0 && CVX_RARE(ovPending)) {
+					scanOverflow();
+				}
+				if (!found) {
+					const bool take0 = DIR > 0 ? vis0 : (vis0 && !vis1);
+					const bool take1 = DIR > 0 ? (vis1 && !vis0) : vis1;
+					if (take0 || take1) {
+						found = true;
+						const uint32_t w0 = take0 ? queue.x : queue.z;
+						const uint32_t w1 = take0 ? queue.y : queue.w;
+						elementLength = (int)(w0 >> 16);
+						elementColorsIndex = (int)(w1 & 0xFFFFu);
+						runSpan(w0, elementBoundsMin, elementBoundsMax);
+						vis0 = vis0 && !take0;
+						vis1 = vis1 && !take1;
+					}
+				}
+				if (DIR > 0 && !found && CVX_RARE(ovPending)) {
+					scanOverflow();
+				}
+			}
+			while (COUNT && solidIndex < solidCount) {
 				CVX_COUNT(3);
 				// the walk's k-th solid run is run k of the record's top-down list, or run solidCount - 1 - k for the bottom-up walk
 				const int j = DIR > 0 ? solidIndex : solidCount - 1 - solidIndex;
@@ -661,7 +724,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 				break;
 			}
 			CVX_END(3);
-			if (!found) {
+			if (COUNT ? !found : CVX_RARE(!found)) { // (rendering build: only a lane whose remaining runs beyond the record are all invisible)
 				if (COUNT && solidIndex == solidCount) { consumed = (header.z >> 16) + 1u; } // walked on to the end guard
 				break;
 			}
@@ -930,6 +993,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		curDistLast = ray.distLast;
 		curDistNext = ray.distNext;
 		curScale = voxelScale;
+		curShift = lod;
 		curElementsOff = L.elementsOff;
 		curRunsOff = L.runsOff;
 		const int curLod = lod;
@@ -945,8 +1009,10 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		}
 		const bool nextOutside = (ray.px & maskX) != ray.px || (ray.pz & maskZ) != ray.pz;
 		const uint32_t rec = L.recordsOff + record_offset((ray.px & maskX) >> L.shift, (ray.pz & maskZ) >> L.shift, L.tilesZShift); // clamped into the table
+#ifndef CVX_EXP_LATE_FETCH
 		const uint4 nextHeader = ld4(arena, rec);
 		const uint4 nextQueue = ld4(arena, rec + 16u);
+#endif
 
 		// ---- the current column, exactly as the reference processes it
 		if (COUNT) {
@@ -1002,8 +1068,13 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		if (CVX_RARE(lastColumn || nextOutside)) {
 			return; // far clip reached / left the world: WriteSkybox
 		}
+#ifndef CVX_EXP_LATE_FETCH
 		header = nextHeader;
 		queue = nextQueue;
+#else
+		header = ld4(arena, rec); // straight into the registers of the column just finished: what hides the latency is the next iteration's step + address arithmetic
+		queue = ld4(arena, rec + 16u);
+#endif
 		CVX_END(1);
 	}
 }

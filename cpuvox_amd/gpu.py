@@ -81,7 +81,19 @@ def lib() -> C.CDLL:
     """Load libcpuvox_gpu.so (built in-tree by cpuvox_amd/csrc/Makefile); fails loudly when missing."""
     global _lib
     if _lib is None:
-        path = lib_path()
+        _lib = _bind(lib_path())
+    return _lib
+
+
+def use_library(path: str | None) -> None:
+    """Diagnostics / tests: make another build of the same ABI (an experiment or profiling build) the library that contexts
+    created FROM NOW ON talk to; None returns to the default.  Contexts of the previous library must be closed first."""
+    global _lib
+    _lib = _bind(path) if path else None
+
+
+def _bind(path: str) -> C.CDLL:
+    if True:
         if not os.path.exists(path):
             raise RuntimeError(f"{path} missing: the HIP extension is required (build with `make -C cpuvox_amd/csrc`); there is no CPU fallback")
         _load_torch_hip_runtime_first()
@@ -135,8 +147,7 @@ def lib() -> C.CDLL:
         L.cvx_comm_create_timeout.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_void_p)]
         L.cvx_comm_destroy.argtypes = [C.c_void_p]
         L.cvx_exchange.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        _lib = L
-    return _lib
+    return L
 
 
 class CvxError(RuntimeError):
