@@ -422,8 +422,10 @@ int Launch(cvx_context *ctx, int frameCount, int flags)
 		dim3 grid((unsigned)nTiles), block(CVX_WAVE);
 		if (ctx->countersEnabled) {
 			hipLaunchKernelGGL((cvxk::render_kernel<true>), grid, block, ldsBytes, ctx->stream, ctx->devFrames, ctx->devTiles, ctx->devWorld, ctx->devCounters);
+#ifdef CVX_EXPERIMENTS
 		} else if (ctx->renderStateMachine) {
 			hipLaunchKernelGGL(cvxk::render_sm_kernel, grid, block, ldsBytes, ctx->stream, ctx->devFrames, ctx->devTiles, ctx->devWorld, cvxk::SmParams{ ctx->smThreshold });
+#endif
 		} else {
 			hipLaunchKernelGGL((cvxk::render_kernel<false>), grid, block, ldsBytes, ctx->stream, ctx->devFrames, ctx->devTiles, ctx->devWorld, ctx->devCounters);
 		}
@@ -485,6 +487,7 @@ int cvx_create(int device, cvx_context **out)
 		if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
 			ctx->splitWaveBudget = prop.multiProcessorCount * 16; // measured optimum on MI355X (256 CUs): at most ~4096 waves per launch
 		}
+#ifdef CVX_EXPERIMENTS /* diagnostics of the experiment build only (`make gpu-exp`): the product library reads no environment */
 		if (const char *v = std::getenv("CVX_TILE_SPLIT")) {
 			const int f = std::atoi(v);
 			if (f >= 1 && f <= CVX_WAVE && (f & (f - 1)) == 0) { ctx->forcedSplit = f; }
@@ -511,6 +514,7 @@ int cvx_create(int device, cvx_context **out)
 			const int w = std::atoi(v);
 			if (w >= 1 && w <= 512) { ctx->minMaskWords = w; }
 		}
+#endif
 	}
 	*out = ctx;
 	return CVX_OK;
@@ -693,6 +697,7 @@ int DrawBatch(cvx_context *ctx, int frameCount, const cvx_segment_data *segments
 #endif
 		const std::vector<float> &cost = ctx->hostTileCost;
 		std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+#ifdef CVX_EXPERIMENTS
 		if (const char *v = std::getenv("CVX_TILE_ORDER")) { // diagnostics: how much the launch order matters
 			if (!std::strcmp(v, "reverse")) {
 				std::reverse(order.begin(), order.end());
@@ -706,6 +711,7 @@ int DrawBatch(cvx_context *ctx, int frameCount, const cvx_segment_data *segments
 				}
 			}
 		}
+#endif
 		// Small batches (a single interactive frame is ~60 tiles on a chip with 1024 SIMDs): every tile is cut into 2, 4, ...
 		// 64 sub-tiles of consecutive rays, one wave each.  A wave's cost per column step is the union of what its rays
 		// need, so narrower waves finish sooner; with few waves there are idle SIMDs to run them on (1 frame: 6.7 -> 4.0 ms at
@@ -1044,7 +1050,8 @@ int cvx_debug_occupancy(cvx_context *ctx, int64_t ldsBytes, int *blocksPerCU)
 	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
 	if (!blocksPerCU) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "blocksPerCU is NULL"); }
 	CVX_HIP(ctx, hipSetDevice(ctx->device));
-	CVX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, cvxk::render_kernel<false>, CVX_WAVE, (size_t)ldsBytes));
+	const int waveThreads = CVX_WAVE;
+	CVX_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(blocksPerCU, cvxk::render_kernel<false>, waveThreads, (size_t)ldsBytes));
 	return CVX_OK;
 }
 
@@ -1066,7 +1073,7 @@ int cvx_debug_section_cycles(cvx_context *ctx, uint64_t out[32], int reset)
 #else
 	(void)reset;
 	for (int i = 0; i < 32; i++) { out[i] = 0; }
-	return Fail(ctx, CVX_ERR_NOT_READY, "library was not built with -DCVX_PROFILE_SECTIONS (diagnostic build)");
+	return Fail(ctx, CVX_ERR_NOT_READY, "this is not the section-profile build of the library (make gpu-prof)");
 #endif
 }
 
@@ -1088,7 +1095,7 @@ int cvx_debug_section_histogram(cvx_context *ctx, uint64_t out[128], int reset)
 #else
 	(void)reset;
 	for (int i = 0; i < 128; i++) { out[i] = 0; }
-	return Fail(ctx, CVX_ERR_NOT_READY, "library was not built with -DCVX_PROFILE_SECTIONS -DCVX_PROFILE_COUNTS (diagnostic build)");
+	return Fail(ctx, CVX_ERR_NOT_READY, "this is not the section-count build of the library (make gpu-count)");
 #endif
 }
 

@@ -284,12 +284,15 @@ __device__ __forceinline__ float clip_max(f3 pMin, f3 pMax, float finv) // :109-
 // evaluates at most one "min" clip (against fMax when a1, else against fMin when b1) and at most one "max" clip (against
 // fMax when a2 and not a1, else against fMin when b2); the arithmetic of each is the tree's own, so the values are the
 // same, but divergent lanes of a wave now share one instance of each division sequence instead of six.
-__device__ __forceinline__ bool clip_world_bounds(f3 pMin, f3 pMax, float fMin, float fMax, float invFMin, float invFMax, float &minLerp, float &maxLerp)
+// `straddles` = pMin lies below the window and pMax above it (the ordinary view of a world column: its foot under the lowest free
+// pixel, its top over the highest): minLerp then comes from the clip against fMin, maxLerp from the clip against fMax, nothing is clipped away.
+__device__ __forceinline__ bool clip_world_bounds(f3 pMin, f3 pMax, float fMin, float fMax, float invFMin, float invFMax, float &minLerp, float &maxLerp, bool &straddles)
 {
 	const bool a1 = pMin.x > pMin.z * fMax;
 	const bool a2 = pMax.x > pMax.z * fMax;
 	const bool b1 = pMin.x < pMin.z * fMin;
 	const bool b2 = pMax.x < pMax.z * fMin;
+	straddles = !a1 && b1 && a2;
 	const bool needMin = a1 || b1;
 	const bool needMax = a1 ? b2 : (a2 || b2);
 	const float lo = clip_min(pMin, pMax, a1 ? invFMax : invFMin);
@@ -562,8 +565,9 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			float clipLastMinLerp, clipLastMaxLerp, clipNextMinLerp, clipNextMaxLerp;
 			// CameraData.cs:103,111.  frustumBounds = (integer pixel in [-1, 16385]) -/+ 0.501: magnitude in [0.499, 16386], always "safe"
 			const float invFrustumMin = quot_safe(1.0f, recip_safe(frustumBoundsMin)), invFrustumMax = quot_safe(1.0f, recip_safe(frustumBoundsMax));
-			const bool clippedLast = clip_world_bounds(camSpaceMinLast, camSpaceMaxLast, frustumBoundsMin, frustumBoundsMax, invFrustumMin, invFrustumMax, clipLastMinLerp, clipLastMaxLerp);
-			const bool clippedNext = clip_world_bounds(camSpaceMinNext, camSpaceMaxNext, frustumBoundsMin, frustumBoundsMax, invFrustumMin, invFrustumMax, clipNextMinLerp, clipNextMaxLerp);
+			bool straddlesLast, straddlesNext;
+			const bool clippedLast = clip_world_bounds(camSpaceMinLast, camSpaceMaxLast, frustumBoundsMin, frustumBoundsMax, invFrustumMin, invFrustumMax, clipLastMinLerp, clipLastMaxLerp, straddlesLast);
+			const bool clippedNext = clip_world_bounds(camSpaceMinNext, camSpaceMaxNext, frustumBoundsMin, frustumBoundsMax, invFrustumMin, invFrustumMax, clipNextMinLerp, clipNextMaxLerp, straddlesNext);
 
 			// (:297-299 leaves here when both ends are outside the window; that exit is taken together with the next one below --
 			// nothing in between has an effect that survives the end of the ray)
@@ -579,33 +583,47 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			const f3 maxClipA = f3_lerp(camSpaceMinLast, camSpaceMaxLast, clipLastMaxLerp);
 			const f3 minClipB = f3_lerp(camSpaceMinNext, camSpaceMaxNext, clipNextMinLerp);
 			const f3 maxClipB = f3_lerp(camSpaceMinNext, camSpaceMaxNext, clipNextMaxLerp);
-			float minNext = minClipB.x / minClipB.z;
-			float minLast = minClipA.x / minClipA.z;
-			float maxNext = maxClipB.x / maxClipB.z;
-			float maxLast = maxClipA.x / maxClipA.z;
-			if (maxNext < minNext) { float t = maxNext; maxNext = minNext; minNext = t; }
-			if (maxLast < minLast) { float t = maxLast; maxLast = minLast; minLast = t; }
-			// (hw_min / hw_max: the results only go through floor / ceil and (int), which map -0 and +0 to the same 0)
-			const float camSpaceClippedMin = clippedLast ? minNext : (clippedNext ? minLast : hw_min(minLast, minNext));
-			const float camSpaceClippedMax = clippedLast ? maxNext : (clippedNext ? maxLast : hw_max(maxLast, maxNext));
-
 			worldBoundsMin = floorf(worldBoundsMin);
 			worldBoundsMax = ceilf(worldBoundsMax);
 
-			const int writableMinPixel = f2i_floor(camSpaceClippedMin);
-			const int writableMaxPixel = f2i(ceilf(camSpaceClippedMax));
+			// :337-421 project the four clipped points (x / z), order them, and take floor(min) / ceil(max) as the writable pixel range, which
+			// can end the ray (:399-403) or move nextFreePixelMin / Max inwards (:405-416).  Only those two INTEGERS are ever used.  In the
+			// ordinary case -- both ends straddle the window, so the min points were clipped against frustumBoundsMin = k - 0.501 and the max
+			// points against frustumBoundsMax = m + 0.501 (k <= nextFreePixelMin <= nextFreePixelMax <= m, integers: ReducePixelHorizon :682,694) --
+			// a clipped point lies ON its bound up to rounding.  If the residual |x - f * z| (as computed, error < 2^-23 |f z| <= 0.002 |z|) is
+			// below 0.4 |z|, then x / z = f + r / z lies within 0.402 of f, the correctly rounded quotient too (rounding is monotone), hence
+			// floor(min) = k - 1 and ceil(max) = m + 1 whatever the exact quotients are: min < max (no swap, :339-346), the range contains
+			// [nextFreePixelMin, nextFreePixelMax] (no exit, nothing moves), and neither end was clipped away.  So nothing of :337-421 has any
+			// effect and the four divisions are not needed.  Any lane for which this cannot be shown takes the reference's path below.
+			const auto onBound = [](f3 p, float f) { return fabsf(p.x - f * p.z) < 0.4f * fabsf(p.z); };
+			const bool windowUntouched = !COUNT && straddlesLast && straddlesNext && onBound(minClipA, frustumBoundsMin) && onBound(minClipB, frustumBoundsMin) &&
+			                             onBound(maxClipA, frustumBoundsMax) && onBound(maxClipB, frustumBoundsMax);
+			if (!CVX_USUAL(windowUntouched)) {
+				float minNext = minClipB.x / minClipB.z;
+				float minLast = minClipA.x / minClipA.z;
+				float maxNext = maxClipB.x / maxClipB.z;
+				float maxLast = maxClipA.x / maxClipA.z;
+				if (maxNext < minNext) { float t = maxNext; maxNext = minNext; minNext = t; }
+				if (maxLast < minLast) { float t = maxLast; maxLast = minLast; minLast = t; }
+				// (hw_min / hw_max: the results only go through floor / ceil and (int), which map -0 and +0 to the same 0)
+				const float camSpaceClippedMin = clippedLast ? minNext : (clippedNext ? minLast : hw_min(minLast, minNext));
+				const float camSpaceClippedMax = clippedLast ? maxNext : (clippedNext ? maxLast : hw_max(maxLast, maxNext));
 
-			if (CVX_RARE((clippedLast && clippedNext) || writableMaxPixel < nextFreePixelMin || writableMinPixel > nextFreePixelMax)) {
-				return false;
-			}
-			if (writableMinPixel > nextFreePixelMin) {
-				nextFreePixelMin = scan_up(seen, sshift, writableMinPixel, omax);
-			}
-			if (writableMaxPixel < nextFreePixelMax) {
-				nextFreePixelMax = scan_down(seen, sshift, writableMaxPixel, omin);
-			}
-			if (COUNT && nextFreePixelMin > nextFreePixelMax) {
-				return false; // :419 (the rendering build notices at the end of the column)
+				const int writableMinPixel = f2i_floor(camSpaceClippedMin);
+				const int writableMaxPixel = f2i(ceilf(camSpaceClippedMax));
+
+				if (CVX_RARE((clippedLast && clippedNext) || writableMaxPixel < nextFreePixelMin || writableMinPixel > nextFreePixelMax)) {
+					return false;
+				}
+				if (writableMinPixel > nextFreePixelMin) {
+					nextFreePixelMin = scan_up(seen, sshift, writableMinPixel, omax);
+				}
+				if (writableMaxPixel < nextFreePixelMax) {
+					nextFreePixelMax = scan_down(seen, sshift, writableMaxPixel, omin);
+				}
+				if (COUNT && nextFreePixelMin > nextFreePixelMax) {
+					return false; // :419 (the rendering build notices at the end of the column)
+				}
 			}
 		}
 
@@ -1198,7 +1216,9 @@ __global__ __launch_bounds__(CVX_WAVE, CVX_WAVES_PER_SIMD) void render_kernel(co
 }
 
 } // namespace cvxk
+#ifdef CVX_EXPERIMENTS /* `make gpu-exp`: the state-machine render kernel of round 2 (slower; kept as the record of that experiment) */
 #include "cvx_render_sm.h"
+#endif
 namespace cvxk {
 
 // ---------------------------------------------------------------------------

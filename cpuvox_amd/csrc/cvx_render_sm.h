@@ -276,9 +276,10 @@ __device__ __forceinline__ void trace_wave_sm(const DevFrame &F, const DevSegmen
 				camSpacePair(curDistLast, camSpaceMinLast, camSpaceMaxLast);
 				camSpacePair(curDistNext, camSpaceMinNext, camSpaceMaxNext);
 				float clipLastMinLerp, clipLastMaxLerp, clipNextMinLerp, clipNextMaxLerp;
+				bool straddlesUnused_;
 				const float invFrustumMin = quot_safe(1.0f, recip_safe(frustumBoundsMin)), invFrustumMax = quot_safe(1.0f, recip_safe(frustumBoundsMax));
-				const bool clippedLast = clip_world_bounds(camSpaceMinLast, camSpaceMaxLast, frustumBoundsMin, frustumBoundsMax, invFrustumMin, invFrustumMax, clipLastMinLerp, clipLastMaxLerp);
-				const bool clippedNext = clip_world_bounds(camSpaceMinNext, camSpaceMaxNext, frustumBoundsMin, frustumBoundsMax, invFrustumMin, invFrustumMax, clipNextMinLerp, clipNextMaxLerp);
+				const bool clippedLast = clip_world_bounds(camSpaceMinLast, camSpaceMaxLast, frustumBoundsMin, frustumBoundsMax, invFrustumMin, invFrustumMax, clipLastMinLerp, clipLastMaxLerp, straddlesUnused_);
+				const bool clippedNext = clip_world_bounds(camSpaceMinNext, camSpaceMaxNext, frustumBoundsMin, frustumBoundsMax, invFrustumMin, invFrustumMax, clipNextMinLerp, clipNextMaxLerp, straddlesUnused_);
 				const bool minFromLast = !clippedLast && (clippedNext || clipLastMinLerp < clipNextMinLerp);
 				const bool maxFromLast = !clippedLast && (clippedNext || clipLastMaxLerp > clipNextMaxLerp);
 				worldBoundsMin = m_lerp(0.0f, worldMaxY, minFromLast ? clipLastMinLerp : clipNextMinLerp);

@@ -47,6 +47,19 @@ def test_gpu_code_object_is_gfx950():
     assert b"gfx950" in data
 
 
+def test_product_library_reads_no_environment_and_holds_one_render_kernel():
+    """`strings libcpuvox_gpu.so | grep CVX_` is empty: no diagnostic environment switch, no experiment kernel in the shipped library
+    (those live in the -DCVX_EXPERIMENTS build, libcpuvox_gpu_exp.so, which the tests of the switches load explicitly)."""
+    data = open(os.path.join(ROOT, "cpuvox_amd", "libcpuvox_gpu.so"), "rb").read()
+    assert b"CVX_" not in data
+    assert b"getenv" not in data, "the product library must not look at the caller's environment"
+    assert b"render_sm_kernel" not in data
+    assert data.count(b"_ZN4cvxk13render_kernelILb0E") > 0 and data.count(b"_ZN4cvxk13render_kernelILb1E") > 0
+    exp = os.path.join(ROOT, "cpuvox_amd", "libcpuvox_gpu_exp.so")
+    if os.path.exists(exp):
+        assert b"CVX_TILE_SPLIT" in open(exp, "rb").read()
+
+
 def test_product_fails_loudly_without_a_device():
     """No CPU fallback: without a HIP device context creation raises (on a GPU box it succeeds)."""
     import torch

@@ -35,6 +35,18 @@ def contexts():
         ctx.close()
 
 
+@pytest.fixture
+def exp_library(monkeypatch):
+    """The experiment build (make gpu-exp, -DCVX_EXPERIMENTS): the only build that reads the diagnostic CVX_* environment switches
+    and contains the state-machine kernel.  The product library reads no environment (tests/test_abi.py)."""
+    path = os.path.join(os.path.dirname(gpu.lib_path()), "libcpuvox_gpu_exp.so")
+    if not os.path.exists(path):
+        pytest.skip("libcpuvox_gpu_exp.so not built (make -C cpuvox_amd/csrc gpu-exp)")
+    gpu.use_library(path)
+    yield monkeypatch
+    gpu.use_library(None)
+
+
 def _render_gpu(ctx, fr, counters=False):
     ctx.enable_counters(counters)
     ctx.clear_raybuffers(0, CLEAR)
@@ -243,10 +255,10 @@ def test_world_with_device_built_lods_renders_identically(contexts):
 
 
 @pytest.mark.parametrize("split", [1, 2, 16, 64])
-def test_sub_tile_split_is_invisible(split, monkeypatch):
+def test_sub_tile_split_is_invisible(split, exp_library):
     """Small batches are rendered with tiles cut into sub-tiles of 64 / split rays per wave (DrawBatch); the raybuffers and the
     counters must not depend on the cut (CVX_TILE_SPLIT pins the factor; the other tests run with the automatic choice)."""
-    monkeypatch.setenv("CVX_TILE_SPLIT", str(split))
+    exp_library.setenv("CVX_TILE_SPLIT", str(split))
     ctx = gpu.Context(0)
     try:
         for name in ("mill256_t075", "proc256_t04_lod8"):
@@ -263,7 +275,8 @@ def test_sub_tile_split_is_invisible(split, monkeypatch):
 
 
 @pytest.mark.parametrize("order", ["reverse", "random", "pixels8", "middle"])
-def test_launch_order_is_invisible(order, monkeypatch):
+def test_launch_order_is_invisible(order, exp_library):
+    monkeypatch = exp_library
     """The tiles of a batch are launched longest-first by an estimate (column visits of the tile's longer edge ray, EstimateTileCost); the estimate and
     the order are scheduling only -- every tile writes its own rows -- so any order gives the same raybuffers."""
     if order.startswith("pixels"):
@@ -290,7 +303,8 @@ def test_launch_order_is_invisible(order, monkeypatch):
 
 
 @pytest.mark.parametrize("threshold", [0, 1, 64])
-def test_state_machine_kernel_is_bit_exact(threshold, monkeypatch):
+def test_state_machine_kernel_is_bit_exact(threshold, exp_library):
+    monkeypatch = exp_library
     """CVX_RENDER_SM=1 selects render_sm_kernel (cvx_render_sm.h): the same per-ray arithmetic, but the wave schedules the blocks of
     ExecuteRay per lane instead of walking all rays column by column.  An experiment (slower, profiles/r02_experiments.md) kept
     behind the switch; its pixels must not depend on the schedule: default thresholds, every non-empty block per pass (1),
