@@ -414,6 +414,8 @@ def main():
         },
     }
 
+    if not args.pmc_csv and N == 1:
+        args.pmc_csv = find_counter_summary(args)
     if args.pmc_csv:
         # Counter summary of a rocprofv3 --pmc run of THIS command and build (tools/pmc_passes.sh + tools/pmc_aggregate.py); never a
         # committed file of another build.  rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB per dispatch (fabric requests of the L2,
@@ -423,7 +425,7 @@ def main():
 
         try:
             with open(args.pmc_csv, newline="") as fh:
-                counters = {row["counter"]: float(row["mean_per_launch"]) for row in csv.DictReader(fh)}
+                counters = {row["counter"]: float(row["mean_per_launch"]) for row in csv.DictReader(l for l in fh if not l.startswith("#"))}
             fetch, write = counters["FETCH_SIZE"] * 1024, counters["WRITE_SIZE"] * 1024
             launches = max(1, k_draws)
             pixel_bytes = 4 * sum(pixels[s] for s in steps) / launches
@@ -433,7 +435,7 @@ def main():
                 "algorithmic_pixel_bytes": int(pixel_bytes), "write_amplification": round(write / max(1.0, pixel_bytes), 3),
                 "tcc_hit_rate": (round(counters["TCC_HIT_sum"] / max(1.0, counters["TCC_HIT_sum"] + counters["TCC_MISS_sum"]), 4)
                                  if "TCC_HIT_sum" in counters and "TCC_MISS_sum" in counters else None),
-                "source": f"{os.path.relpath(args.pmc_csv, ROOT)}: rocprofv3 --pmc passes of this command, per launch of render_kernel<false>",
+                "source": f"{os.path.relpath(args.pmc_csv, ROOT)}: rocprofv3 --pmc passes of this workload with this build (stamped with the sha-256 of the kernel sources), per launch of render_kernel<false>",
             }
         except (OSError, KeyError, ValueError) as e:
             result["roofline"]["traffic_detail"] = {"error": f"unreadable counter summary {args.pmc_csv}: {e}"}
@@ -545,6 +547,43 @@ def main():
         dist.destroy_process_group()
     if parity_failed:
         raise SystemExit("bench.py: the GPU raybuffers of the timed frames differ from the CPU oracle")
+
+
+def find_counter_summary(args):
+    """profiles/rNN_pmc_render_kernel.csv of THIS build and THIS workload, or None.  tools/profile_round.sh stamps the file with the
+    sha-256 of the kernel sources and the bench arguments of the counter passes (tools/pmc_aggregate.py); counters of another
+    build or of another shape are never attached to the line (roofline.traffic stays null)."""
+    import glob
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        from pmc_aggregate import kernel_sources_sha256
+
+        mine = kernel_sources_sha256()
+    except Exception:  # noqa: BLE001
+        return None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_render_kernel.csv")), reverse=True):
+        try:
+            with open(path) as fh:
+                first = fh.readline()
+            if not first.startswith("#"):
+                continue
+            stamp = json.loads(first[1:])
+            ap = argparse.ArgumentParser()
+            for flag, typ in (("--frames", int), ("--width", int), ("--height", int), ("--world", str), ("--lod-error", float), ("--pose-range", str)):
+                ap.add_argument(flag, type=typ, default=None)
+            theirs, _ = ap.parse_known_args(stamp.get("bench_args", []))
+            same = all((getattr(theirs, k) if getattr(theirs, k) is not None else parse_default(k)) == getattr(args, k)
+                       for k in ("frames", "width", "height", "world", "lod_error", "pose_range"))
+            if stamp.get("kernel_sources_sha256") == mine and same:
+                return path
+        except (OSError, ValueError):
+            continue
+    return None
+
+
+def parse_default(name):
+    return {"frames": 512, "width": 1920, "height": 1080, "world": "proc2048", "lod_error": 1.0, "pose_range": None}[name]
 
 
 def cpu_baseline(ws, frames, W, H, budget_s: float, parity_frames=()):

@@ -73,7 +73,6 @@ struct cvx_context {
 	void *blitParamsDev = nullptr;   // BlitParams of a batch (device) + their pinned staging copy
 	void *blitParamsPinned = nullptr;
 	int blitParamsCapacity = 0;
-	int blitBlockX = 64, blitBlockY = 4; // CVX_BLIT_BLOCK=XxY (diagnostics)
 	uint32_t *staging = nullptr;
 	size_t stagingBytes = 0;
 

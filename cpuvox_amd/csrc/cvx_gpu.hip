@@ -496,10 +496,6 @@ int cvx_create(int device, cvx_context **out)
 			const int w = std::atoi(v);
 			if (w >= 64 && w <= 40960) { ctx->maxWaveMaskWords = w; ctx->maxWaveMaskWordsAuto = false; }
 		}
-		if (const char *v = std::getenv("CVX_BLIT_BLOCK")) { // diagnostics: thread block of the Phase-2 kernels, e.g. 16x16
-			int bx = 0, by = 0;
-			if (std::sscanf(v, "%dx%d", &bx, &by) == 2 && bx >= 1 && by >= 1 && bx * by >= 64 && bx * by <= 1024 && (bx * by) % 64 == 0) { ctx->blitBlockX = bx; ctx->blitBlockY = by; }
-		}
 		if (const char *v = std::getenv("CVX_TILE_COST_MIDDLE_RAY")) { ctx->tileCostMiddleRay = std::atoi(v) != 0; } // diagnostics: the round-1 estimate
 		if (const char *v = std::getenv("CVX_TILE_COST_PIXELS")) { // diagnostics
 			const float w = (float)std::atof(v);
@@ -864,13 +860,19 @@ int cvx_read_raybuffer(cvx_context *ctx, int bufferIndex, int which, int firstRa
 static void FillBlitParams(const cvx_context *ctx, int bufferIndex, cvxk::BlitParams &p)
 {
 	const LastDraw &last = ctx->last[(size_t)bufferIndex];
-	p.vpX = last.vp[0];
-	p.vpY = last.vp[1];
+	const float ax = last.vp[0], ay = last.vp[1];
 	for (int s = 0; s < 4; s++) {
-		p.minX[s] = last.segments[s].MinScreen[0];
-		p.minY[s] = last.segments[s].MinScreen[1];
-		p.maxX[s] = last.segments[s].MaxScreen[0];
-		p.maxY[s] = last.segments[s].MaxScreen[1];
+		// edge functions of the triangle (VP, MaxScreen, MinScreen), float32 operation by operation as tests/oraclelib.blit_reference does
+		const float qx = last.segments[s].MinScreen[0], qy = last.segments[s].MinScreen[1];
+		const float bx = last.segments[s].MaxScreen[0], by = last.segments[s].MaxScreen[1];
+		const float den = (by - qy) * (ax - qx) + (qx - bx) * (ay - qy);
+		const float inv = 1.0f / den;
+		p.qx[s] = qx;
+		p.qy[s] = qy;
+		p.a0[s] = (by - qy) * inv;
+		p.b0[s] = (qx - bx) * inv;
+		p.a1[s] = (qy - ay) * inv;
+		p.b1[s] = (ax - qx) * inv;
 		p.rayCount[s] = last.segments[s].RayCount;
 		p.tileBase[s] = last.tileBase[s];
 	}
@@ -915,8 +917,8 @@ int cvx_blit_segments_batch(cvx_context *ctx, int firstBufferIndex, int frameCou
 	cvxk::BlitParams *host = static_cast<cvxk::BlitParams *>(ctx->blitParamsPinned);
 	for (int f = 0; f < frameCount; f++) { FillBlitParams(ctx, firstBufferIndex + f, host[f]); }
 	CVX_HIP(ctx, hipMemcpyAsync(ctx->blitParamsDev, host, sizeof(cvxk::BlitParams) * (size_t)frameCount, hipMemcpyHostToDevice, ctx->stream));
-	dim3 block((unsigned)ctx->blitBlockX, (unsigned)ctx->blitBlockY);
-	dim3 grid((unsigned)((ctx->resX + ctx->blitBlockX - 1) / ctx->blitBlockX), (unsigned)((ctx->resY + ctx->blitBlockY - 1) / ctx->blitBlockY), (unsigned)frameCount);
+	dim3 block(256); // one workgroup per 64 x 64 pixels (blit_block)
+	dim3 grid((unsigned)((ctx->resX + CVX_BLIT_TILE - 1) / CVX_BLIT_TILE), (unsigned)((ctx->resY + CVX_BLIT_TILE - 1) / CVX_BLIT_TILE), (unsigned)frameCount);
 	hipLaunchKernelGGL(cvxk::blit_batch_kernel, grid, block, 0, ctx->stream, ctx->poolBaseTD, ctx->poolBaseLR, ctx->poolBytesTD / 4, ctx->poolBytesLR / 4, images,
 	                   static_cast<const cvxk::BlitParams *>(ctx->blitParamsDev), firstBufferIndex);
 	CVX_HIP(ctx, hipGetLastError());
@@ -933,7 +935,7 @@ int cvx_blit_segments(cvx_context *ctx, int bufferIndex, void *dstHost)
 	CVX_HIP(ctx, hipSetDevice(ctx->device));
 	cvxk::BlitParams p;
 	FillBlitParams(ctx, bufferIndex, p);
-	dim3 block((unsigned)ctx->blitBlockX, (unsigned)ctx->blitBlockY), grid((unsigned)((p.width + ctx->blitBlockX - 1) / ctx->blitBlockX), (unsigned)((p.height + ctx->blitBlockY - 1) / ctx->blitBlockY));
+	dim3 block(256), grid((unsigned)((p.width + CVX_BLIT_TILE - 1) / CVX_BLIT_TILE), (unsigned)((p.height + CVX_BLIT_ROWS_SINGLE - 1) / CVX_BLIT_ROWS_SINGLE));
 	hipLaunchKernelGGL(cvxk::blit_kernel, grid, block, 0, ctx->stream, ctx->poolTD[(size_t)bufferIndex], ctx->poolLR[(size_t)bufferIndex], ctx->screen, p);
 	CVX_HIP(ctx, hipGetLastError());
 	if (dstHost) {

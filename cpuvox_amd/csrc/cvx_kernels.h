@@ -1282,75 +1282,189 @@ __global__ void copy_rows_kernel(uint4 *__restrict__ poolTD, uint4 *__restrict__
 // ---------------------------------------------------------------------------
 // Phase 2: RenderManager.BlitSegments (RenderManager.cs:199-256) +
 // RayBufferBlit.shader frag (:48-64), evaluated at pixel centres.  Rule (ours,
-// Unity's rasteriser is not restated): barycentrics of the centre in triangle
-// (VP, MaxScreen, MinScreen); first segment whose weights are all >= 0 wins;
-// x = wMax / (wMax + wMin); ray = clamp(floor(x * RayCount), 0, RayCount-1).
+// Unity's rasteriser is not restated; tests/oraclelib.blit_reference is the same
+// arithmetic in numpy, float32 operation by operation): for segment s with
+// triangle (VP = a, MaxScreen = b, MinScreen = q) the host computes ONCE per frame
+//     den = (b.y - q.y) * (a.x - q.x) + (q.x - b.x) * (a.y - q.y),  inv = 1 / den
+//     A0 = (b.y - q.y) * inv, B0 = (q.x - b.x) * inv      (weight of VP)
+//     A1 = (q.y - a.y) * inv, B1 = (a.x - q.x) * inv      (weight of MaxScreen)
+// and a pixel centre c evaluates two edge functions per segment, no division:
+//     wVp = A0 * (c.x - q.x) + B0 * (c.y - q.y),  wMax = A1 * (c.x - q.x) + B1 * (c.y - q.y),  wMin = 1 - wVp - wMax
+// first segment whose weights are all >= 0 wins; x = wMax / (wMax + wMin) (uv.x / (uv.x + uv.y), RayBufferBlit.shader:56);
+// ray = clamp(floor(x * RayCount), 0, RayCount - 1).
 // ---------------------------------------------------------------------------
 struct BlitParams {
-	float vpX, vpY;
-	float minX[4], minY[4], maxX[4], maxY[4];
+	float qx[4], qy[4];                 // MinScreen
+	float a0[4], b0[4], a1[4], b1[4];   // edge functions, see above
 	int rayCount[4];
 	int tileBase[4];
 	int width, height;
 	uint32_t clearColor;
 };
 
-__device__ __forceinline__ uint32_t blit_pixel(const uint32_t *__restrict__ poolTD, const uint32_t *__restrict__ poolLR, const BlitParams &p, int px, int py)
+// Barycentric weights of pixel centre (px, py) in the triangle of segment s (see above)
+__device__ __forceinline__ void blit_weights(const BlitParams &p, int s, int px, int py, float &wVp, float &wMax, float &wMin)
 {
-	const float cx = (float)px + 0.5f, cy = (float)py + 0.5f;
-	uint32_t color = p.clearColor;
-#pragma unroll // (the four segments' parameters are then fetched once, ahead of the tests, instead of per iteration: 8.4 -> 8.0 us per 1080p frame)
+	const float dx = ((float)px + 0.5f) - p.qx[s], dy = ((float)py + 0.5f) - p.qy[s];
+	wVp = p.a0[s] * dx + p.b0[s] * dy;
+	wMax = p.a1[s] * dx + p.b1[s] * dy;
+	wMin = 1.0f - wVp - wMax;
+}
+__device__ __forceinline__ int blit_ray(int rc, float wMax, float wMin)
+{
+	const float x = wMax / (wMax + wMin);
+	float rf = floorf(x * (float)rc);
+	rf = fminf(fmaxf(rf, 0.0f), (float)(rc - 1));
+	return (rf == rf) ? (int)rf : 0;
+}
+// Which segment owns pixel (px, py) and which ray of it: segment 0..3 (-1: none) and the ray index.
+__device__ __forceinline__ int blit_classify(const BlitParams &p, int px, int py, int &ray)
+{
+	ray = 0;
+#pragma unroll // (the four segments' parameters are then fetched once, ahead of the tests, instead of per iteration)
 	for (int s = 0; s < 4; s++) {
 		const int rc = p.rayCount[s];
 		if (rc <= 0) {
 			continue;
 		}
-		const float ax = p.vpX, ay = p.vpY, bx = p.maxX[s], by = p.maxY[s], qx = p.minX[s], qy = p.minY[s];
-		const float den = (by - qy) * (ax - qx) + (qx - bx) * (ay - qy);
-		const float wVp = ((by - qy) * (cx - qx) + (qx - bx) * (cy - qy)) / den;
-		const float wMax = ((qy - ay) * (cx - qx) + (ax - qx) * (cy - qy)) / den;
-		const float wMin = 1.0f - wVp - wMax;
+		float wVp, wMax, wMin;
+		blit_weights(p, s, px, py, wVp, wMax, wMin);
 		if (wVp >= 0.0f && wMax >= 0.0f && wMin >= 0.0f) {
-			const float x = wMax / (wMax + wMin);
-			float rf = floorf(x * (float)rc);
-			rf = fminf(fmaxf(rf, 0.0f), (float)(rc - 1));
-			const int ray = (rf == rf) ? (int)rf : 0;
-			const int tile = p.tileBase[s] + (ray >> 6);
-			if (s < 2) {
-				color = poolTD[((size_t)tile * (size_t)p.height + (size_t)py) * CVX_WAVE + (ray & 63)];
-			} else {
-				color = poolLR[((size_t)tile * (size_t)p.width + (size_t)px) * CVX_WAVE + (ray & 63)];
-			}
-			break;
+			ray = blit_ray(rc, wMax, wMin);
+			return s;
 		}
 	}
-	return color;
+	return -1;
+}
+__device__ __forceinline__ uint32_t blit_fetch_td(const uint32_t *__restrict__ poolTD, const BlitParams &p, int s, int ray, int py)
+{
+	return poolTD[((uint32_t)(p.tileBase[s] + (ray >> 6)) * (uint32_t)p.height + (uint32_t)py) * CVX_WAVE + (uint32_t)(ray & 63)]; // (a pool is < 2^32 pixels: cvx_set_resolution)
+}
+__device__ __forceinline__ uint32_t blit_fetch_lr(const uint32_t *__restrict__ poolLR, const BlitParams &p, int s, int ray, int px)
+{
+	return poolLR[((uint32_t)(p.tileBase[s] + (ray >> 6)) * (uint32_t)p.width + (uint32_t)px) * CVX_WAVE + (uint32_t)(ray & 63)];
 }
 
-__global__ void blit_kernel(const uint32_t *__restrict__ poolTD, const uint32_t *__restrict__ poolLR, uint32_t *__restrict__ screen, BlitParams p)
+// One workgroup (256 threads) per 64 x 64 block of the screen.
+// * Pixels of the top / bottom segments read raybuffer pixel `py` of their ray: lanes along x touch neighbouring rays of one 256-byte
+//   tile row.  Pixels of the left / right segments read raybuffer pixel `px` of their ray, and there the neighbouring rays belong to
+//   pixels ABOVE each other: read with lanes along x every lane would hit a row of its own (a 64-byte sector per 4 bytes used).  So
+//   those pixels are gathered with lanes along y into an LDS tile first (row stride 65 words: conflict-free both ways), and the
+//   x-major pass that stores the screen rows takes them from there.
+// * Most blocks lie inside ONE segment (the four triangles only meet along the diagonals through the vanishing point), and then the
+//   per-pixel search over the segments is not needed.  A block is taken as owned by segment s when, at its four corner pixels, all three
+//   weights of s are >= 1e-3 and for every earlier segment one and the same weight is <= -1e-3 (or it has no rays): the weights are
+//   linear in the pixel position up to rounding (|products| < 1000 is checked, so a computed weight is within ~1e-4 of the exact linear
+//   form), hence inside the block all weights of s stay > 0 and that weight of each earlier segment stays < 0 -- the search would pick
+//   s for every pixel.  Any other block searches per pixel.  Same pixels either way.
+#define CVX_BLIT_TILE 64
+// TH = rows per workgroup: 64 for a batch of frames (a 64 x 64 block: longest contiguous raybuffer spans either way), 16 for a single
+// frame (four times the workgroups: one 1080p frame alone is only 510 blocks of 64 x 64 on a chip with 256 CUs)
+template <int TH>
+__device__ __forceinline__ void blit_block(const uint32_t *__restrict__ poolTD, const uint32_t *__restrict__ poolLR, uint32_t *__restrict__ screen, const BlitParams &p)
 {
-	const int px = blockIdx.x * blockDim.x + threadIdx.x;
-	const int py = blockIdx.y * blockDim.y + threadIdx.y;
-	if (px >= p.width || py >= p.height) {
+	__shared__ uint32_t tile[TH * (CVX_BLIT_TILE + 1)];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6; // 4 waves
+	const int x0 = blockIdx.x * CVX_BLIT_TILE, y0 = blockIdx.y * TH;
+	const int x1 = min(x0 + CVX_BLIT_TILE, p.width) - 1, y1 = min(y0 + TH, p.height) - 1;
+
+	// ---- owner of the whole block, if provable: lane = corner + 4 * segment (every wave computes the same)
+	int owner = -1;
+	{
+		const int c = lane & 3, sg = (lane >> 2) & 3;
+		float wVp, wMax, wMin;
+		blit_weights(p, sg, (c & 1) ? x1 : x0, (c & 2) ? y1 : y0, wVp, wMax, wMin);
+		const float dxm = fmaxf(fabsf((float)x0 - p.qx[sg]), fabsf((float)x1 + 1.0f - p.qx[sg])), dym = fmaxf(fabsf((float)y0 - p.qy[sg]), fabsf((float)y1 + 1.0f - p.qy[sg]));
+		const bool bounded = fmaxf(fmaxf(fabsf(p.a0[sg]), fabsf(p.a1[sg])) * dxm, fmaxf(fabsf(p.b0[sg]), fabsf(p.b1[sg])) * dym) < 1000.0f; // false for NaN / inf
+		const bool use = lane < 16 && p.rayCount[sg] > 0;
+		const unsigned long long in = __ballot(use && bounded && wVp >= 1e-3f && wMax >= 1e-3f && wMin >= 1e-3f);
+		const unsigned long long outA = __ballot(lane < 16 && (!use || (bounded && wVp <= -1e-3f)));
+		const unsigned long long outB = __ballot(lane < 16 && (!use || (bounded && wMax <= -1e-3f)));
+		const unsigned long long outC = __ballot(lane < 16 && (!use || (bounded && wMin <= -1e-3f)));
+		bool earlierOut = true;
+#pragma unroll
+		for (int s = 0; s < 4; s++) {
+			const unsigned int m = 15u << (4 * s);
+			if (owner < 0 && earlierOut && ((unsigned int)in & m) == m) { owner = s; }
+			earlierOut = earlierOut && ((((unsigned int)outA & m) == m) || (((unsigned int)outB & m) == m) || (((unsigned int)outC & m) == m));
+		}
+	}
+	const uint32_t W = (uint32_t)p.width;
+
+	if (owner >= 0 && owner < 2) { // top / bottom: straight from the raybuffer, x-major
+		const int px = x0 + lane, rc = p.rayCount[owner];
+		if (px <= x1) {
+#pragma unroll 4 // (four independent fetches in flight per lane)
+			for (int py = y0 + wave; py <= y1; py += 4) {
+				float wVp, wMax, wMin;
+				blit_weights(p, owner, px, py, wVp, wMax, wMin);
+				screen[(uint32_t)py * W + (uint32_t)px] = blit_fetch_td(poolTD, p, owner, blit_ray(rc, wMax, wMin), py);
+			}
+		}
 		return;
 	}
-	screen[(size_t)py * (size_t)p.width + (size_t)px] = blit_pixel(poolTD, poolLR, p, px, py);
+	// y-major gather of the left / right pixels: lane = (row inside the block, one of 64 / TH columns); a wave takes every fourth column group
+	{
+		const int py = y0 + (lane & (TH - 1));
+		if (py <= y1) {
+#pragma unroll 4
+			for (int c = wave * (64 / TH) + lane / TH; x0 + c <= x1; c += 4 * (64 / TH)) {
+				const int px = x0 + c;
+				int ray, s = owner;
+				if (owner >= 0) {
+					float wVp, wMax, wMin;
+					blit_weights(p, owner, px, py, wVp, wMax, wMin);
+					ray = blit_ray(p.rayCount[owner], wMax, wMin);
+				} else {
+					s = blit_classify(p, px, py, ray);
+				}
+				if (s >= 2) {
+					tile[(lane & (TH - 1)) * (CVX_BLIT_TILE + 1) + c] = blit_fetch_lr(poolLR, p, s, ray, px);
+				}
+			}
+		}
+	}
+	__syncthreads();
+	// x-major: wave w takes rows w, w + 4, ...; lane = column inside the block
+	{
+		const int px = x0 + lane;
+		if (px <= x1) {
+#pragma unroll 4
+			for (int r = wave; y0 + r <= y1; r += 4) {
+				const int py = y0 + r;
+				uint32_t color = p.clearColor;
+				if (owner >= 2) {
+					color = tile[r * (CVX_BLIT_TILE + 1) + lane];
+				} else {
+					int ray;
+					const int s = blit_classify(p, px, py, ray);
+					if (s >= 2) {
+						color = tile[r * (CVX_BLIT_TILE + 1) + lane];
+					} else if (s >= 0) {
+						color = blit_fetch_td(poolTD, p, s, ray, py);
+					}
+				}
+				screen[(uint32_t)py * W + (uint32_t)px] = color;
+			}
+		}
+	}
+}
+
+#define CVX_BLIT_ROWS_SINGLE 16
+__global__ __launch_bounds__(256) void blit_kernel(const uint32_t *__restrict__ poolTD, const uint32_t *__restrict__ poolLR, uint32_t *__restrict__ screen, BlitParams p)
+{
+	blit_block<CVX_BLIT_ROWS_SINGLE>(poolTD, poolLR, screen, p);
 }
 
 // Phase 2 of a whole batch in one launch (blockIdx.z = frame): buffer firstBuffer + f -> image f of `screens`.  All raybuffers of a
 // kind are one allocation, strideTD / strideLR = uint32 words per buffer.
-__global__ void blit_batch_kernel(const uint32_t *__restrict__ poolBaseTD, const uint32_t *__restrict__ poolBaseLR, size_t strideTD, size_t strideLR,
-                                  uint32_t *__restrict__ screens, const BlitParams *__restrict__ params, int firstBuffer)
+__global__ __launch_bounds__(256) void blit_batch_kernel(const uint32_t *__restrict__ poolBaseTD, const uint32_t *__restrict__ poolBaseLR, size_t strideTD, size_t strideLR,
+                                                         uint32_t *__restrict__ screens, const BlitParams *__restrict__ params, int firstBuffer)
 {
 	const int f = blockIdx.z;
 	const BlitParams &p = params[f];
-	const int px = blockIdx.x * blockDim.x + threadIdx.x;
-	const int py = blockIdx.y * blockDim.y + threadIdx.y;
-	if (px >= p.width || py >= p.height) {
-		return;
-	}
 	const size_t b = (size_t)(firstBuffer + f);
-	screens[((size_t)f * (size_t)p.height + (size_t)py) * (size_t)p.width + (size_t)px] = blit_pixel(poolBaseTD + b * strideTD, poolBaseLR + b * strideLR, p, px, py);
+	blit_block<CVX_BLIT_TILE>(poolBaseTD + b * strideTD, poolBaseLR + b * strideLR, screens + (size_t)f * (size_t)p.height * (size_t)p.width, p);
 }
 
 // ---------------------------------------------------------------------------

@@ -148,8 +148,10 @@ def blit_reference(frame, td: np.ndarray, lr: np.ndarray, width: int, height: in
     """Phase-2 rule (RenderManager.BlitSegments RenderManager.cs:199-256 +
     RayBufferBlit.shader:48-64) evaluated at pixel centres, numpy.
 
-    For segment s with triangle (VP, MaxScreen, MinScreen): barycentric
-    weights (w_vp, w_max, w_min) of the pixel centre; inside when all >= 0;
+    For segment s with triangle (VP = a, MaxScreen = b, MinScreen = q): per-frame edge functions
+    inv = 1 / den, A0 = (b.y - q.y) inv, B0 = (q.x - b.x) inv, A1 = (q.y - a.y) inv, B1 = (a.x - q.x) inv (float32),
+    per pixel centre c: w_vp = A0 (c.x - q.x) + B0 (c.y - q.y), w_max = A1 (c.x - q.x) + B1 (c.y - q.y),
+    w_min = 1 - w_vp - w_max (the same float32 operations, in the same order, as blit_pixel in cvx_kernels.h); inside when all >= 0;
     x = w_max / (w_max + w_min); ray = min(floor(x * RayCount), RayCount-1);
     colour = raybuffer[ray + offset][screen y (segments 0,1) or screen x (2,3)].
     Returns image[H, W] uint32, row 0 = bottom (Unity screen space).
@@ -169,9 +171,14 @@ def blit_reference(frame, td: np.ndarray, lr: np.ndarray, width: int, height: in
         bx, by = np.float32(seg.MaxScreen[0]), np.float32(seg.MaxScreen[1])
         qx, qy = np.float32(seg.MinScreen[0]), np.float32(seg.MinScreen[1])
         den = (by - qy) * (ax - qx) + (qx - bx) * (ay - qy)
-        w_vp = ((by - qy) * (cx - qx) + (qx - bx) * (cy - qy)) / den
-        w_max = ((qy - ay) * (cx - qx) + (ax - qx) * (cy - qy)) / den
-        w_min = np.float32(1.0) - w_vp - w_max
+        with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+            inv = np.float32(1.0) / den
+            a0, b0 = (by - qy) * inv, (qx - bx) * inv
+            a1, b1 = (qy - ay) * inv, (ax - qx) * inv
+            dx, dy = cx - qx, cy - qy
+            w_vp = a0 * dx + b0 * dy
+            w_max = a1 * dx + b1 * dy
+            w_min = np.float32(1.0) - w_vp - w_max
         inside = (w_vp >= 0) & (w_max >= 0) & (w_min >= 0) & ~done
         with np.errstate(divide="ignore", invalid="ignore"):
             x = w_max / (w_max + w_min)

@@ -1,14 +1,31 @@
 #!/usr/bin/env python3
 """Aggregate the per-pass rocprofv3 --pmc outputs of tools/pmc_passes.sh into one small CSV.
 
-usage: tools/pmc_aggregate.py <pmc outdir> <kernel substring> > profiles/rNN_pmc_render_kernel.csv
+usage: tools/pmc_aggregate.py <pmc outdir> <kernel substring> [bench args of the passes...] > profiles/rNN_pmc_render_kernel.csv
+(first line: a comment with the sha-256 of the kernel sources and the bench arguments the counters were collected with)
 
 For every counter: mean over the dispatches of kernels whose name contains the substring (counter values of one
 dispatch are summed over the rows rocprofv3 emits for it, e.g. one row per XCD/instance)."""
 import csv
 import glob
+import hashlib
+import json
+import os
 import sys
 from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNEL_SOURCES = ["cvx_kernels.h", "cvx_device.h", "cvx_context.h", "cvx_downsample.h", "cvx_gpu.hip", "cvx_world.hip", "cvx_shard.hip", "Makefile"]
+
+
+def kernel_sources_sha256() -> str:
+    """Identity of the build a counter file belongs to: the sources libcpuvox_gpu.so is compiled from (bench.py only attaches
+    counter traffic to its line when this matches the tree it runs from)."""
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "cpuvox_amd", "csrc", name), "rb") as fh:
+            h.update(name.encode() + b"\0" + fh.read())
+    return h.hexdigest()
 
 
 def main():
@@ -24,6 +41,8 @@ def main():
     for (_, _, name), v in per_dispatch.items():
         sums[name] += v
         counts[name] += 1
+    stamp = {"kernel_sources_sha256": kernel_sources_sha256(), "bench_args": sys.argv[3:]}
+    print("# " + json.dumps(stamp))
     print("counter,mean_per_launch,launches")
     for name in sums:
         print(f"{name},{sums[name] / counts[name]:.6g},{counts[name]}")

@@ -11,7 +11,7 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace"
 find "$OUT/trace" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
 # 2. counter passes (separate runs, --pmc only)
 bash "$R/tools/pmc_passes.sh" "$OUT/pmc" --cpu-seconds 0 --latency-frames 0 --steps 3 --warmup 1 > "$OUT/pmc_passes.log" 2>&1
-python3 "$R/tools/pmc_aggregate.py" "$OUT/pmc" "render_kernel<false>" > "$OUT/pmc_render_kernel.csv"
+python3 "$R/tools/pmc_aggregate.py" "$OUT/pmc" "render_kernel<false>" --cpu-seconds 0 --latency-frames 0 --steps 3 --warmup 1 > "$OUT/pmc_render_kernel.csv"
 # 3. the bench line of this build with the measured traffic attached (and the CPU leg, parity check, latency legs)
 timeout 900 python3 "$R/bench.py" --pmc-csv "$OUT/pmc_render_kernel.csv" > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
 # 4. SQ counters (128 frames per launch)
