@@ -57,6 +57,9 @@ def parse_args():
     ap.add_argument("--pmc-csv", default=None, help="counter summary of a rocprofv3 --pmc run of THIS command (tools/pmc_passes.sh + "
                     "tools/pmc_aggregate.py): fills roofline.traffic from FETCH_SIZE + WRITE_SIZE; without it traffic is null")
     ap.add_argument("--comm-timeout", type=float, default=180.0, help="N > 1: seconds cvx_comm_create may wait for the peers (then exit code 4)")
+    ap.add_argument("--gather", choices=("raybuffer", "image"), default="raybuffer",
+                    help="N > 1: what travels to the display rank of a frame -- the other ranks' raybuffer tile rows (BASELINE.json's north_star; default) or "
+                         "their pixels of the finished image (cvx_image_*: each rank runs Phase 2 for its own tiles; W*H*4 bytes per frame in total)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' = single-GPU rehearsal of the N > 1 path "
                     "(all ranks share the visible GPUs, tiles travel through host memory)")
     return ap.parse_args()
@@ -242,14 +245,54 @@ def main():
                 exchange_path = f"torch.distributed batch_isend_irecv (C-ABI exchange unavailable: {why or 'a peer could not create the communicator'})"
         else:
             exchange_path = "torch.distributed batch_isend_irecv"
-        send_rows = max(1, max(p.send_total for p in plans))
-        disp_rows = max(1, max(p.disp_total for p in plans))
+        raybuffer_areas = args.gather != "image"  # (the image gather has its own, smaller buffers: below)
+        send_rows = max(1, max(p.send_total for p in plans)) if raybuffer_areas else 1
+        disp_rows = max(1, max(p.disp_total for p in plans)) if raybuffer_areas else 1
         # two parities: step s+1 renders into the other pair while step s is still on the wire
         send = [torch.zeros((send_rows, cdist.TILE_RAYS), dtype=torch.int32, device=device) for _ in range(2)]
         disp = [torch.zeros((disp_rows, cdist.TILE_RAYS), dtype=torch.int32, device=device) for _ in range(2)]
-        tile_outs = [plans[s].tile_out(send[s % 2].data_ptr(), disp[s % 2].data_ptr()) for s in range(total_steps)]
+        tile_outs = [plans[s].tile_out(send[s % 2].data_ptr(), disp[s % 2].data_ptr()) for s in range(total_steps)] if raybuffer_areas else None
         s_render, s_exchange = torch.cuda.Stream(device), torch.cuda.Stream(device)
         ctx.set_stream(s_render.cuda_stream)
+
+    image_mode = sharded and args.gather == "image"
+    img_plans = img_store = img_send = img_recv = img_images = None
+    if image_mode:
+        # image gather: compact local tile store + pixel streams + the images this rank displays, two parities like the raybuffer areas
+        img_plans = [gpu.ImagePlan(ctx, pk, W, H, rank, N) for pk in packed]
+        words = lambda n: max(1, int(n))  # noqa: E731
+        img_store = [torch.zeros(words(max(p.local_store_bytes for p in img_plans) // 4), dtype=torch.int32, device=device) for _ in range(2)]
+        img_send = [torch.zeros(words(max(p.send_pixels for p in img_plans)), dtype=torch.int32, device=device) for _ in range(2)]
+        img_recv = [torch.zeros(words(max(p.recv_pixels for p in img_plans)), dtype=torch.int32, device=device) for _ in range(2)]
+        img_images = [torch.zeros((words(max(p.images for p in img_plans)), H, W), dtype=torch.int32, device=device) for _ in range(2)]
+        tile_outs = [img_plans[s].tile_out(img_store[s % 2].data_ptr()) for s in range(total_steps)]
+        if not comm:
+            exchange_path = "torch.distributed batch_isend_irecv of the pixel streams" + (f" ({exchange_path})" if exchange_path and "unavailable" in exchange_path else "")
+        else:
+            exchange_path = "cvx_image_exchange (grouped ncclSend/ncclRecv of pixel streams inside libcpuvox_gpu, library-owned communicator)"
+
+    def image_exchange_torch(plan, send, recv):
+        """The pixel streams with torch.distributed P2P ops (fallback / gloo rehearsal: staged through host memory)."""
+        via_host = dist.get_backend() == "gloo"
+        if via_host:
+            torch.cuda.current_stream().synchronize()
+        ops, received = [], []
+        for peer in range(N):
+            if peer == rank:
+                continue
+            s0, sn, r0, rn = plan.transfer(peer)
+            if sn:
+                ops.append(dist.P2POp(dist.isend, send[s0:s0 + sn].cpu() if via_host else send[s0:s0 + sn], peer))
+            if rn:
+                buf = torch.empty(rn, dtype=recv.dtype) if via_host else recv[r0:r0 + rn]
+                received.append((r0, rn, buf))
+                ops.append(dist.P2POp(dist.irecv, buf, peer))
+        for req in (dist.batch_isend_irecv(ops) if ops else []):
+            req.wait()
+        if via_host:
+            for r0, rn, buf in received:
+                recv[r0:r0 + rn].copy_(buf)
+            torch.cuda.current_stream().synchronize()
 
     def draw(s: int, flags: int):
         if sharded:
@@ -284,7 +327,15 @@ def main():
             ev_render.record(s_render)
             s_exchange.wait_event(ev_render)
             with torch.cuda.stream(s_exchange):
-                if comm:
+                if image_mode:
+                    ip = img_plans[s]
+                    ip.pack(ctx, s_exchange.cuda_stream, img_store[par].data_ptr(), img_send[par].data_ptr(), img_images[par].data_ptr())
+                    if comm:
+                        ip.exchange(ctx, comm, s_exchange.cuda_stream, img_send[par].data_ptr(), img_recv[par].data_ptr())
+                    else:
+                        image_exchange_torch(ip, img_send[par], img_recv[par])
+                    ip.unpack(ctx, s_exchange.cuda_stream, img_recv[par].data_ptr(), img_images[par].data_ptr())
+                elif comm:
                     native_plans[s].exchange(ctx, comm, s_exchange.cuda_stream, send[par].data_ptr(), disp[par].data_ptr())
                 else:
                     for req in plans[s].exchange(send[par], disp[par]):
@@ -303,6 +354,11 @@ def main():
         mine = [b for b in range(G) if b % N == rank][:2]
         for b in mine:
             fr = steps_frames[step][b]
+            if image_mode:  # the gathered image == Phase 2 of the same frame rendered whole on this rank
+                ctx.clear_raybuffers(0, 0)
+                ctx.draw_segments(fr, 0)
+                ok = ok and bool((img_images[step % 2][b // N].cpu().numpy().view(np.uint32) == ctx.blit_segments(0)).all())
+                continue
             rc = [s.RayCount for s in fr.segments]
             a_td, a_lr = plans[step].assemble(disp[step % 2], b, rc, W, H)
             ctx.clear_raybuffers(0, 0)
@@ -358,7 +414,9 @@ def main():
     k_bytes = sum(alg_bytes[s] for s in steps)
     k_sec = k_ms_total / 1e3
     achieved = k_bytes / k_sec / 1e9
-    if sharded and not args.no_exchange:
+    if image_mode and not args.no_exchange:
+        parallelism = f"ray-tile sharding x{N}, per-rank Phase 2 + P2P gather of the finished pixels (image gather)" + (" overlapped with the next render" if overlap else "")
+    elif sharded and not args.no_exchange:
         parallelism = f"ray-tile sharding x{N}, zero-copy placement + RCCL P2P tile exchange" + (" overlapped with the next render" if overlap else "")
     else:
         parallelism = f"ray-tile sharding x{N}" + (" (no exchange)" if sharded else "")
@@ -394,7 +452,8 @@ def main():
             "ranks_seen": ranks_seen,
             "exchange_verified": exchange_verified,
             "exchange_path": exchange_path,
-            "exchange_bytes_per_step_per_gpu": int(np.mean([p.send_total for p in plans]) * 256) if sharded else 0,
+            "gather": args.gather if sharded else None,
+            "exchange_bytes_per_step_per_gpu": (int(np.mean([p.send_pixels for p in img_plans]) * 4) if image_mode else int(np.mean([p.send_total for p in plans]) * 256)) if sharded else 0,
             "world_dims": list(dims),
             "lod_distances": lods,
             "lod_visits_per_step": [int(np.mean([lod_visits[s][l] for s in steps])) for l in range(6)],

@@ -3,6 +3,8 @@
 // See include/cpuvox_gpu.h for the contract of every entry point.
 #include <hip/hip_runtime.h>
 
+#include <memory>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -857,14 +859,13 @@ int cvx_read_raybuffer(cvx_context *ctx, int bufferIndex, int which, int firstRa
 	return CVX_OK;
 }
 
-static void FillBlitParams(const cvx_context *ctx, int bufferIndex, cvxk::BlitParams &p)
+// edge functions of the four triangles (VP, MaxScreen, MinScreen), float32 operation by operation, mirrored by the numpy rule the tests compare against (blit_reference)
+static void MakeBlitParams(const cvx_segment_data *segments, const float *vp, const int *tileBase, int W, int H, cvxk::BlitParams &p)
 {
-	const LastDraw &last = ctx->last[(size_t)bufferIndex];
-	const float ax = last.vp[0], ay = last.vp[1];
+	const float ax = vp[0], ay = vp[1];
 	for (int s = 0; s < 4; s++) {
-		// edge functions of the triangle (VP, MaxScreen, MinScreen), float32 operation by operation as tests/oraclelib.blit_reference does
-		const float qx = last.segments[s].MinScreen[0], qy = last.segments[s].MinScreen[1];
-		const float bx = last.segments[s].MaxScreen[0], by = last.segments[s].MaxScreen[1];
+		const float qx = segments[s].MinScreen[0], qy = segments[s].MinScreen[1];
+		const float bx = segments[s].MaxScreen[0], by = segments[s].MaxScreen[1];
 		const float den = (by - qy) * (ax - qx) + (qx - bx) * (ay - qy);
 		const float inv = 1.0f / den;
 		p.qx[s] = qx;
@@ -873,12 +874,18 @@ static void FillBlitParams(const cvx_context *ctx, int bufferIndex, cvxk::BlitPa
 		p.b0[s] = (qx - bx) * inv;
 		p.a1[s] = (qy - ay) * inv;
 		p.b1[s] = (ax - qx) * inv;
-		p.rayCount[s] = last.segments[s].RayCount;
-		p.tileBase[s] = last.tileBase[s];
+		p.rayCount[s] = segments[s].RayCount;
+		p.tileBase[s] = tileBase ? tileBase[s] : 0;
 	}
-	p.width = ctx->resX;
-	p.height = ctx->resY;
+	p.width = W;
+	p.height = H;
 	p.clearColor = 0u;
+}
+
+static void FillBlitParams(const cvx_context *ctx, int bufferIndex, cvxk::BlitParams &p)
+{
+	const LastDraw &last = ctx->last[(size_t)bufferIndex];
+	MakeBlitParams(last.segments, last.vp, last.tileBase, ctx->resX, ctx->resY, p);
 }
 
 int cvx_blit_segments_batch(cvx_context *ctx, int firstBufferIndex, int frameCount, void *dstDevice, void **imagesDevice)
@@ -943,6 +950,183 @@ int cvx_blit_segments(cvx_context *ctx, int bufferIndex, void *dstHost)
 		CVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	}
 	return CVX_OK;
+}
+
+// ---- multi-GPU image gather (include/cpuvox_gpu.h; kernels and the scheme: cvx_kernels.h, "Multi-GPU image gather") ---------------
+struct cvx_image_plan {
+	int rank = 0, worldSize = 1, W = 0, H = 0, frameCount = 0;
+	int64_t tileCount = 0;         // canonical tiles of the batch (all ranks)
+	int64_t localSlots = 0;        // tiles I render
+	size_t tileStrideWords = 0;    // words per tile in my compact store: 64 * max(W, H)
+	int imagesMine = 0;            // frames I display
+	std::vector<cvxk::ImageFrame> frames;
+	std::vector<int64_t> firstTile; // canonical index of the first tile of every frame (frameCount + 1)
+	std::vector<int64_t> sendStart, recvStart; // N + 1 boundaries, pixels
+	cvxk::ImageFrame *devFrames = nullptr;
+	int *devRowBase = nullptr;
+	long long *devTotals = nullptr;
+};
+
+void cvx_image_plan_destroy(cvx_image_plan *plan)
+{
+	if (!plan) { return; }
+	if (plan->devFrames) { (void)hipFree(plan->devFrames); }
+	if (plan->devRowBase) { (void)hipFree(plan->devRowBase); }
+	if (plan->devTotals) { (void)hipFree(plan->devTotals); }
+	delete plan;
+}
+
+int cvx_image_plan_create(cvx_context *ctx, int frameCount, const cvx_segment_data *segments, const float *vanishingPoints, int screenWidth, int screenHeight,
+                          int rank, int worldSize, cvx_image_plan **out)
+{
+	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
+	if (!out) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "out is NULL"); }
+	*out = nullptr;
+	if (frameCount <= 0 || !segments || !vanishingPoints || screenWidth <= 0 || screenHeight <= 0 || screenWidth > 16384 || screenHeight > 16384 ||
+	    worldSize < 1 || worldSize > 8 || rank < 0 || rank >= worldSize) {
+		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "bad image plan arguments (at most 8 ranks)");
+	}
+	CVX_HIP(ctx, hipSetDevice(ctx->device));
+	std::unique_ptr<cvx_image_plan, void (*)(cvx_image_plan *)> p(new (std::nothrow) cvx_image_plan(), cvx_image_plan_destroy);
+	if (!p) { return Fail(ctx, CVX_ERR_HIP, "out of host memory"); }
+	const int N = worldSize, W = screenWidth, H = screenHeight;
+	try {
+		p->rank = rank; p->worldSize = N; p->W = W; p->H = H; p->frameCount = frameCount;
+		p->tileStrideWords = (size_t)CVX_WAVE * (size_t)std::max(W, H);
+		p->frames.resize((size_t)frameCount);
+		p->firstTile.assign((size_t)frameCount + 1, 0);
+		int64_t slots = 0;
+		for (int b = 0; b < frameCount; b++) {
+			cvxk::ImageFrame &F = p->frames[(size_t)b];
+			std::memset(&F, 0, sizeof F);
+			MakeBlitParams(segments + (size_t)b * 4, vanishingPoints + (size_t)b * 2, nullptr, W, H, F.p);
+			int t = 0;
+			for (int s = 0; s < 4; s++) {
+				F.tileStart[s] = t;
+				const int rays = segments[(size_t)b * 4 + s].RayCount > 0 ? segments[(size_t)b * 4 + s].RayCount : 0;
+				t += (rays + CVX_WAVE - 1) / CVX_WAVE;
+			}
+			F.root = b % N;
+			F.imageSlot = b / N;
+			F.localSlotBase = (int)slots;
+			slots += (t > rank) ? (t - rank + N - 1) / N : 0; // canonical tiles rank, rank + N, ... of this frame
+			p->firstTile[(size_t)b + 1] = p->firstTile[(size_t)b] + t;
+			if (F.root == rank) { p->imagesMine++; }
+		}
+		if (slots > 0x7FFFFFFF) { return Fail(ctx, CVX_ERR_CAPACITY, "too many tiles for one image plan"); }
+		p->localSlots = slots;
+		p->tileCount = p->firstTile[(size_t)frameCount];
+	} catch (const std::exception &e) {
+		return Fail(ctx, CVX_ERR_HIP, "cvx_image_plan_create: %s", e.what());
+	}
+	const size_t frameBytes = sizeof(cvxk::ImageFrame) * (size_t)frameCount;
+	CVX_HIP(ctx, hipMalloc((void **)&p->devFrames, frameBytes));
+	CVX_HIP(ctx, hipMalloc((void **)&p->devRowBase, sizeof(int) * 8 * (size_t)H * (size_t)frameCount));
+	CVX_HIP(ctx, hipMalloc((void **)&p->devTotals, sizeof(long long) * 8 * (size_t)frameCount));
+	CVX_HIP(ctx, hipMemcpyAsync(p->devFrames, p->frames.data(), frameBytes, hipMemcpyHostToDevice, ctx->stream));
+	hipLaunchKernelGGL(cvxk::image_count_kernel, dim3((unsigned)H, (unsigned)frameCount), dim3(CVX_WAVE), 0, ctx->stream, p->devFrames, N, p->devRowBase);
+	hipLaunchKernelGGL(cvxk::image_scan_kernel, dim3((unsigned)((frameCount * 8 + 255) / 256)), dim3(256), 0, ctx->stream, frameCount, H, p->devRowBase, p->devTotals);
+	CVX_HIP(ctx, hipGetLastError());
+	std::vector<long long> totals((size_t)frameCount * 8);
+	CVX_HIP(ctx, hipMemcpyAsync(totals.data(), p->devTotals, sizeof(long long) * totals.size(), hipMemcpyDeviceToHost, ctx->stream));
+	CVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	// streams: (src -> dst) holds the frames dst displays, in frame order, each with src's pixels of it in row-major order
+	std::vector<int64_t> sendLen((size_t)N, 0), recvLen((size_t)N, 0);
+	for (int b = 0; b < frameCount; b++) {
+		const int root = b % N;
+		if (root == rank) {
+			for (int r = 0; r < N; r++) { if (r != rank) { recvLen[(size_t)r] += totals[(size_t)b * 8 + (size_t)r]; } }
+		} else {
+			sendLen[(size_t)root] += totals[(size_t)b * 8 + (size_t)rank];
+		}
+	}
+	p->sendStart.assign((size_t)N + 1, 0);
+	p->recvStart.assign((size_t)N + 1, 0);
+	for (int i = 0; i < N; i++) {
+		p->sendStart[(size_t)i + 1] = p->sendStart[(size_t)i] + sendLen[(size_t)i];
+		p->recvStart[(size_t)i + 1] = p->recvStart[(size_t)i] + recvLen[(size_t)i];
+	}
+	std::vector<int64_t> sendAt(p->sendStart.begin(), p->sendStart.end() - 1), recvAt(p->recvStart.begin(), p->recvStart.end() - 1);
+	for (int b = 0; b < frameCount; b++) {
+		cvxk::ImageFrame &F = p->frames[(size_t)b];
+		if (F.root == rank) {
+			for (int r = 0; r < N; r++) {
+				if (r == rank) { continue; }
+				F.recvBase[r] = recvAt[(size_t)r];
+				recvAt[(size_t)r] += totals[(size_t)b * 8 + (size_t)r];
+			}
+		} else {
+			F.sendBase = sendAt[(size_t)F.root];
+			sendAt[(size_t)F.root] += totals[(size_t)b * 8 + (size_t)rank];
+		}
+	}
+	CVX_HIP(ctx, hipMemcpyAsync(p->devFrames, p->frames.data(), frameBytes, hipMemcpyHostToDevice, ctx->stream));
+	CVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	*out = p.release();
+	return CVX_OK;
+}
+
+int64_t cvx_image_plan_tile_count(const cvx_image_plan *plan) { return plan ? plan->tileCount : 0; }
+
+int cvx_image_plan_sizes(const cvx_image_plan *plan, int64_t *localStoreBytes, int64_t *sendPixels, int64_t *recvPixels, int32_t *imagesDisplayed)
+{
+	if (!plan) { return Fail(nullptr, CVX_ERR_INVALID_ARGUMENT, "plan is NULL"); }
+	if (localStoreBytes) { *localStoreBytes = (int64_t)((size_t)plan->localSlots * plan->tileStrideWords * 4); }
+	if (sendPixels) { *sendPixels = plan->sendStart.back(); }
+	if (recvPixels) { *recvPixels = plan->recvStart.back(); }
+	if (imagesDisplayed) { *imagesDisplayed = plan->imagesMine; }
+	return CVX_OK;
+}
+
+int cvx_image_plan_transfer(const cvx_image_plan *plan, int peer, int64_t *sendPixel, int64_t *sendPixels, int64_t *recvPixel, int64_t *recvPixels)
+{
+	if (!plan || peer < 0 || peer >= plan->worldSize || !sendPixel || !sendPixels || !recvPixel || !recvPixels) { return Fail(nullptr, CVX_ERR_INVALID_ARGUMENT, "bad arguments"); }
+	*sendPixel = plan->sendStart[(size_t)peer];
+	*sendPixels = plan->sendStart[(size_t)peer + 1] - plan->sendStart[(size_t)peer];
+	*recvPixel = plan->recvStart[(size_t)peer];
+	*recvPixels = plan->recvStart[(size_t)peer + 1] - plan->recvStart[(size_t)peer];
+	return CVX_OK;
+}
+
+int cvx_image_plan_tile_out(const cvx_image_plan *plan, void *localStore, uint64_t *tileOut)
+{
+	if (!plan || !tileOut) { return Fail(nullptr, CVX_ERR_INVALID_ARGUMENT, "bad arguments"); }
+	const int N = plan->worldSize;
+	for (int b = 0; b < plan->frameCount; b++) {
+		const int64_t first = plan->firstTile[(size_t)b], tiles = plan->firstTile[(size_t)b + 1] - first;
+		for (int64_t c = 0; c < tiles; c++) {
+			tileOut[first + c] = (c % N == plan->rank)
+			                         ? (uint64_t)(uintptr_t)localStore + (uint64_t)((size_t)(plan->frames[(size_t)b].localSlotBase + c / N) * plan->tileStrideWords * 4)
+			                         : 0;
+		}
+	}
+	return CVX_OK;
+}
+
+static int ImageGatherLaunch(cvx_context *ctx, const cvx_image_plan *plan, void *hipStream, int unpack, const void *localStore, void *sendStream, const void *recvStream, void *images)
+{
+	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
+	if (!plan || !images) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "plan / images missing"); }
+	CVX_HIP(ctx, hipSetDevice(ctx->device));
+	hipStream_t st = hipStream ? (hipStream_t)hipStream : ctx->stream;
+	hipLaunchKernelGGL(cvxk::image_gather_kernel, dim3((unsigned)plan->H, (unsigned)plan->frameCount), dim3(CVX_WAVE), 0, st, plan->devFrames, plan->worldSize, plan->rank, unpack,
+	                   plan->devRowBase, static_cast<const uint32_t *>(localStore), plan->tileStrideWords, static_cast<uint32_t *>(sendStream),
+	                   static_cast<const uint32_t *>(recvStream), static_cast<uint32_t *>(images));
+	CVX_HIP(ctx, hipGetLastError());
+	return CVX_OK;
+}
+
+int cvx_image_pack(cvx_context *ctx, const cvx_image_plan *plan, void *hipStream, const void *localStore, void *sendStream, void *images)
+{
+	if (plan && (!localStore || (plan->sendStart.back() > 0 && !sendStream))) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "local store / send stream missing"); }
+	return ImageGatherLaunch(ctx, plan, hipStream, 0, localStore, sendStream, nullptr, images);
+}
+
+int cvx_image_unpack(cvx_context *ctx, const cvx_image_plan *plan, void *hipStream, const void *recvStream, void *images)
+{
+	if (plan && plan->recvStart.back() > 0 && !recvStream) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "receive stream missing"); }
+	if (plan && plan->recvStart.back() == 0) { return CVX_OK; }
+	return ImageGatherLaunch(ctx, plan, hipStream, 1, nullptr, nullptr, recvStream, images);
 }
 
 int cvx_raybuffer_device_ptr(cvx_context *ctx, int bufferIndex, int which, void **ptr, int64_t *bytes)

@@ -1282,7 +1282,7 @@ __global__ void copy_rows_kernel(uint4 *__restrict__ poolTD, uint4 *__restrict__
 // ---------------------------------------------------------------------------
 // Phase 2: RenderManager.BlitSegments (RenderManager.cs:199-256) +
 // RayBufferBlit.shader frag (:48-64), evaluated at pixel centres.  Rule (ours,
-// Unity's rasteriser is not restated; tests/oraclelib.blit_reference is the same
+// Unity's rasteriser is not restated; the test-side numpy rule (blit_reference in tests/) is the same
 // arithmetic in numpy, float32 operation by operation): for segment s with
 // triangle (VP = a, MaxScreen = b, MinScreen = q) the host computes ONCE per frame
 //     den = (b.y - q.y) * (a.x - q.x) + (q.x - b.x) * (a.y - q.y),  inv = 1 / den
@@ -1465,6 +1465,118 @@ __global__ __launch_bounds__(256) void blit_batch_kernel(const uint32_t *__restr
 	const BlitParams &p = params[f];
 	const size_t b = (size_t)(firstBuffer + f);
 	blit_block<CVX_BLIT_TILE>(poolBaseTD + b * strideTD, poolBaseLR + b * strideLR, screens + (size_t)f * (size_t)p.height * (size_t)p.width, p);
+}
+
+// ---------------------------------------------------------------------------
+// Multi-GPU image gather (the alternative to the raybuffer gather): every rank blits only the pixels whose ray lies
+// in a 64-ray tile it rendered itself, and the display rank of a frame receives W x H pixels IN TOTAL instead of the raybuffer
+// rows of the other ranks' tiles (~2x the screen).  A pixel's owner is a pure function of the frame's segments: canonical tile
+// c = tileStart[segment] + ray / 64 of the pixel (blit_classify), owner = c % N.  Sender and receiver walk the image in the same
+// order (row by row, left to right), so rank r's pixels of a frame form one packed stream whose positions both sides compute
+// from per-row counts: image_count_kernel (counts per row and rank), image_scan_kernel (row offsets), image_gather_kernel (pack on
+// the rendering rank, unpack on the display rank).  One wave per image row.
+// ---------------------------------------------------------------------------
+struct ImageFrame {
+	BlitParams p;       // tileBase[] is unused here
+	int tileStart[4];   // canonical index (inside the frame) of the first tile of each segment
+	int root;           // display rank of the frame
+	int localSlotBase;  // first slot of this frame in my compact tile store (slot of canonical tile c that I own: localSlotBase + c / N)
+	int imageSlot;      // index of the frame among the frames its root displays
+	int pad;
+	long long sendBase;     // first pixel of (me -> root) for this frame inside my send stream
+	long long recvBase[8];  // root == me: first pixel of (rank r -> me) for this frame inside my receive stream
+};
+
+__device__ __forceinline__ int image_owner(const ImageFrame &F, int N, int px, int py, int &tileCanonical, int &ray, int &seg)
+{
+	seg = blit_classify(F.p, px, py, ray);
+	tileCanonical = seg >= 0 ? F.tileStart[seg] + (ray >> 6) : 0;
+	return seg >= 0 ? tileCanonical % N : -1;
+}
+
+// rowCount[(frame * H + row) * 8 + r] = pixels of the row owned by rank r
+__global__ __launch_bounds__(64) void image_count_kernel(const ImageFrame *__restrict__ frames, int N, int *__restrict__ rowCount)
+{
+	const ImageFrame &F = frames[blockIdx.y];
+	const int row = blockIdx.x, lane = threadIdx.x;
+	int mine = 0; // lane r: count of rank r
+	for (int x0 = 0; x0 < F.p.width; x0 += 64) {
+		const int px = x0 + lane;
+		int c, ray, seg;
+		const int owner = px < F.p.width ? image_owner(F, N, px, row, c, ray, seg) : -1;
+		for (int r = 0; r < N; r++) {
+			const int n = __popcll(__ballot(owner == r));
+			if (lane == r) { mine += n; }
+		}
+	}
+	if (lane < 8) {
+		rowCount[((size_t)blockIdx.y * (size_t)F.p.height + (size_t)row) * 8 + lane] = lane < N ? mine : 0;
+	}
+}
+
+// exclusive scan over the rows of every (frame, rank): rowCount -> row offsets, totals[frame * 8 + r] = pixels of the frame owned by r
+__global__ void image_scan_kernel(int frameCount, int H, int *__restrict__ rowCount, long long *__restrict__ totals)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= frameCount * 8) {
+		return;
+	}
+	const int f = i >> 3, r = i & 7;
+	int running = 0;
+	for (int row = 0; row < H; row++) {
+		int *cell = rowCount + ((size_t)f * (size_t)H + (size_t)row) * 8 + r;
+		const int n = *cell;
+		*cell = running;
+		running += n;
+	}
+	totals[i] = running;
+}
+
+// unpack == 0 (every rank, every frame): my pixels -> the image (frames I display) or my send stream; pixels of no segment belong to the root
+// unpack == 1 (frames I display): the other ranks' pixels, from my receive stream -> the image
+__global__ __launch_bounds__(64) void image_gather_kernel(const ImageFrame *__restrict__ frames, int N, int me, int unpack, const int *__restrict__ rowBase,
+                                                         const uint32_t *__restrict__ localStore, size_t tileStrideWords, uint32_t *__restrict__ sendStream,
+                                                         const uint32_t *__restrict__ recvStream, uint32_t *__restrict__ images)
+{
+	const ImageFrame &F = frames[blockIdx.y];
+	if (unpack && F.root != me) {
+		return;
+	}
+	const int row = blockIdx.x, lane = threadIdx.x, W = F.p.width, H = F.p.height;
+	uint32_t *image = images + (size_t)F.imageSlot * (size_t)W * (size_t)H;
+	const int *base = rowBase + ((size_t)blockIdx.y * (size_t)H + (size_t)row) * 8;
+	int running = lane < 8 ? base[lane] : 0; // lane r: position of rank r's next pixel of this frame
+	for (int x0 = 0; x0 < W; x0 += 64) {
+		const int px = x0 + lane;
+		int c, ray, seg;
+		const int owner = px < W ? image_owner(F, N, px, row, c, ray, seg) : -2;
+		int position = 0;
+		for (int r = 0; r < N; r++) {
+			const unsigned long long b = __ballot(owner == r);
+			const int at = __shfl(running, r);
+			if (owner == r) { position = at + __popcll(b & ((1ull << lane) - 1ull)); }
+			if (lane == r) { running += __popcll(b); }
+		}
+		if (px >= W) {
+			continue;
+		}
+		if (!unpack) {
+			if (owner == me) {
+				const int colLen = seg < 2 ? H : W, y = seg < 2 ? row : px;
+				(void)colLen;
+				const uint32_t v = localStore[(size_t)(F.localSlotBase + c / N) * tileStrideWords + (size_t)y * CVX_WAVE + (size_t)(ray & 63)];
+				if (F.root == me) {
+					image[(size_t)row * (size_t)W + (size_t)px] = v;
+				} else {
+					sendStream[F.sendBase + position] = v;
+				}
+			} else if (owner == -1 && F.root == me) {
+				image[(size_t)row * (size_t)W + (size_t)px] = F.p.clearColor;
+			}
+		} else if (owner >= 0 && owner != me) {
+			image[(size_t)row * (size_t)W + (size_t)px] = recvStream[F.recvBase[owner] + position];
+		}
+	}
 }
 
 // ---------------------------------------------------------------------------

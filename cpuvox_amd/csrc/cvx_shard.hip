@@ -290,4 +290,31 @@ int cvx_exchange(cvx_context *ctx, const cvx_shard_plan *plan, void *comm, void 
 	return CVX_OK;
 }
 
+int cvx_image_exchange(cvx_context *ctx, const cvx_image_plan *plan, void *comm, void *hipStream, void *sendStream, void *recvStream)
+{
+	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
+	if (!plan) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "plan is NULL"); }
+	int64_t total[2] = { 0, 0 };
+	(void)cvx_image_plan_sizes(plan, nullptr, &total[0], &total[1], nullptr);
+	if (total[0] == 0 && total[1] == 0) { return CVX_OK; } // one rank: nothing travels
+	if (!comm || (total[0] > 0 && !sendStream) || (total[1] > 0 && !recvStream)) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "communicator / streams missing"); }
+	Rccl &r = LoadRccl();
+	if (!r.ok) { return Fail(ctx, CVX_ERR_NOT_READY, "librccl could not be loaded"); }
+	CVX_HIP(ctx, hipSetDevice(ctx->device));
+	hipStream_t st = hipStream ? (hipStream_t)hipStream : ctx->stream;
+	ncclResult_t rc = r.groupStart();
+	if (rc != ncclSuccess) { return NcclFail(ctx, r, "ncclGroupStart", rc); }
+	const ncclComm_t c = (ncclComm_t)comm;
+	for (int peer = 0; rc == ncclSuccess; peer++) {
+		int64_t s0, sn, r0, rn;
+		if (cvx_image_plan_transfer(plan, peer, &s0, &sn, &r0, &rn) != CVX_OK) { break; } // past the last rank
+		if (sn > 0) { rc = r.send(static_cast<uint8_t *>(sendStream) + (size_t)s0 * 4, (size_t)sn * 4, ncclInt8, peer, c, st); }
+		if (rc == ncclSuccess && rn > 0) { rc = r.recv(static_cast<uint8_t *>(recvStream) + (size_t)r0 * 4, (size_t)rn * 4, ncclInt8, peer, c, st); }
+	}
+	const ncclResult_t rcEnd = r.groupEnd();
+	if (rc != ncclSuccess) { return NcclFail(ctx, r, "ncclSend / ncclRecv", rc); }
+	if (rcEnd != ncclSuccess) { return NcclFail(ctx, r, "ncclGroupEnd", rcEnd); }
+	return CVX_OK;
+}
+
 } // extern "C"

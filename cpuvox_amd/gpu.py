@@ -32,6 +32,8 @@ EXPORTS = [
     "cvx_world_downsample", "cvx_world_build_lods", "cvx_free", "cvx_debug_section_histogram",
     "cvx_shard_plan_create", "cvx_shard_plan_destroy", "cvx_shard_plan_tile_count", "cvx_shard_plan_sections", "cvx_shard_plan_tile_out", "cvx_shard_plan_transfer",
     "cvx_comm_unique_id", "cvx_comm_create", "cvx_comm_create_timeout", "cvx_comm_destroy", "cvx_exchange",
+    "cvx_image_plan_create", "cvx_image_plan_destroy", "cvx_image_plan_tile_count", "cvx_image_plan_sizes", "cvx_image_plan_transfer",
+    "cvx_image_plan_tile_out", "cvx_image_pack", "cvx_image_exchange", "cvx_image_unpack",
 ]
 
 
@@ -147,6 +149,17 @@ def _bind(path: str) -> C.CDLL:
         L.cvx_comm_create_timeout.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_void_p)]
         L.cvx_comm_destroy.argtypes = [C.c_void_p]
         L.cvx_exchange.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cvx_image_plan_create.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.cvx_image_plan_destroy.argtypes = [C.c_void_p]
+        L.cvx_image_plan_destroy.restype = None
+        L.cvx_image_plan_tile_count.argtypes = [C.c_void_p]
+        L.cvx_image_plan_tile_count.restype = C.c_int64
+        L.cvx_image_plan_sizes.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+        L.cvx_image_plan_transfer.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.cvx_image_plan_tile_out.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cvx_image_pack.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cvx_image_exchange.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cvx_image_unpack.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     return L
 
 
@@ -421,6 +434,54 @@ class NativeShardPlan:
     def close(self) -> None:
         if self._h:
             lib().cvx_shard_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ImagePlan:
+    """cvx_image_plan_* (include/cpuvox_gpu.h): the IMAGE gather of one batch of frames -- every rank blits the pixels of the tiles it
+    rendered, the display rank receives W * H pixels per frame in total.  Needs the GPU (pixel counts per rank are made on the device)."""
+
+    def __init__(self, ctx: "Context", packed, width: int, height: int, rank: int, world_size: int):
+        n, segs, _cams, vps = packed
+        self._keep = packed
+        self._h = C.c_void_p()
+        ctx._check(lib().cvx_image_plan_create(ctx._h, n, C.addressof(segs), C.addressof(vps), width, height, rank, world_size, C.byref(self._h)))
+        self.rank, self.N, self.frames = rank, world_size, n
+        self.tile_count = int(lib().cvx_image_plan_tile_count(self._h))
+        a, b, c, d = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int32()
+        lib().cvx_image_plan_sizes(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d))
+        self.local_store_bytes, self.send_pixels, self.recv_pixels, self.images = a.value, b.value, c.value, d.value
+
+    def tile_out(self, local_store_ptr: int) -> np.ndarray:
+        out = np.zeros(max(1, self.tile_count), dtype=np.uint64)
+        lib().cvx_image_plan_tile_out(self._h, C.c_void_p(local_store_ptr), out.ctypes.data)
+        return out[: self.tile_count]
+
+    def transfer(self, peer: int):
+        """(first send pixel, send pixels, first receive pixel, receive pixels) between this rank and `peer`."""
+        a, b, c, d = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        if lib().cvx_image_plan_transfer(self._h, peer, C.byref(a), C.byref(b), C.byref(c), C.byref(d)) != 0:
+            raise CvxError("cvx_image_plan_transfer failed")
+        return a.value, b.value, c.value, d.value
+
+    def pack(self, ctx: "Context", hip_stream: int | None, local_store_ptr: int, send_ptr: int, images_ptr: int) -> None:
+        ctx._check(lib().cvx_image_pack(ctx._h, self._h, C.c_void_p(hip_stream or 0), C.c_void_p(local_store_ptr), C.c_void_p(send_ptr), C.c_void_p(images_ptr)))
+
+    def exchange(self, ctx: "Context", comm: int, hip_stream: int | None, send_ptr: int, recv_ptr: int) -> None:
+        ctx._check(lib().cvx_image_exchange(ctx._h, self._h, C.c_void_p(comm), C.c_void_p(hip_stream or 0), C.c_void_p(send_ptr), C.c_void_p(recv_ptr)))
+
+    def unpack(self, ctx: "Context", hip_stream: int | None, recv_ptr: int, images_ptr: int) -> None:
+        ctx._check(lib().cvx_image_unpack(ctx._h, self._h, C.c_void_p(hip_stream or 0), C.c_void_p(recv_ptr), C.c_void_p(images_ptr)))
+
+    def close(self) -> None:
+        if self._h:
+            lib().cvx_image_plan_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -110,6 +110,16 @@ namespace CpuVox.Gpu
 		[DllImport(Lib)] public static extern int cvx_comm_create_timeout(IntPtr ctx, void* id128, int rank, int worldSize, double timeoutSeconds, out IntPtr comm);
 		[DllImport(Lib)] public static extern int cvx_comm_destroy(IntPtr comm);
 		[DllImport(Lib)] public static extern int cvx_exchange(IntPtr ctx, IntPtr plan, IntPtr comm, IntPtr hipStream, void* sendBase, void* dispBase);
+		// multi-GPU, image gather: every rank blits its own tiles' pixels, the display rank receives W * H pixels per frame
+		[DllImport(Lib)] public static extern int cvx_image_plan_create(IntPtr ctx, int frameCount, SegmentData* segments, float* vanishingPoints, int screenWidth, int screenHeight, int rank, int worldSize, out IntPtr plan);
+		[DllImport(Lib)] public static extern void cvx_image_plan_destroy(IntPtr plan);
+		[DllImport(Lib)] public static extern long cvx_image_plan_tile_count(IntPtr plan);
+		[DllImport(Lib)] public static extern int cvx_image_plan_sizes(IntPtr plan, out long localStoreBytes, out long sendPixels, out long recvPixels, out int imagesDisplayed);
+		[DllImport(Lib)] public static extern int cvx_image_plan_transfer(IntPtr plan, int peer, out long sendPixel, out long sendPixels, out long recvPixel, out long recvPixels);
+		[DllImport(Lib)] public static extern int cvx_image_plan_tile_out(IntPtr plan, void* localStore, ulong* tileOut);
+		[DllImport(Lib)] public static extern int cvx_image_pack(IntPtr ctx, IntPtr plan, IntPtr hipStream, void* localStore, void* sendStream, void* images);
+		[DllImport(Lib)] public static extern int cvx_image_exchange(IntPtr ctx, IntPtr plan, IntPtr comm, IntPtr hipStream, void* sendStream, void* recvStream);
+		[DllImport(Lib)] public static extern int cvx_image_unpack(IntPtr ctx, IntPtr plan, IntPtr hipStream, void* recvStream, void* images);
 	}
 
 	/// <summary>

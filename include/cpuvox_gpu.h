@@ -186,6 +186,34 @@ int cvx_comm_destroy(void *comm);
 /* The exchange of one batch on hipStream (NULL = the context's stream): returns after enqueueing; order the consumer with the stream. */
 int cvx_exchange(cvx_context *ctx, const cvx_shard_plan *plan, void *comm, void *hipStream, void *sendBase, void *dispBase);
 
+/*
+ * The other way of putting a sharded frame together: the IMAGE gather.  Every rank runs Phase 2
+ * (RenderManager.BlitSegments, RenderManager.cs:199-256 + RayBufferBlit.shader:48-64) for the pixels whose ray lies in a tile it
+ * rendered itself, and the display rank of a frame receives W * H pixels in total instead of the other ranks' raybuffer rows (a
+ * raybuffer is ~2x the pixels of the screen it produces).  Per batch of frames:
+ *     plan = cvx_image_plan_create(ctx, frames, rank, N)        -- counts pixels per rank on the device (one pass over the images)
+ *     cvx_image_plan_tile_out(plan, localStore, out)            -- my tiles go into a compact local store (64 * max(W, H) pixels per tile)
+ *     cvx_draw_segments_placed(ctx, ..., out, CVX_DRAW_ASYNC)
+ *     cvx_image_pack(ctx, plan, stream, localStore, send, images)    -- my pixels: into the images I display, or my send stream
+ *     cvx_image_exchange(ctx, plan, comm, stream, send, recv)        -- one ncclSend + one ncclRecv per peer
+ *     cvx_image_unpack(ctx, plan, stream, recv, images)              -- the peers' pixels of the frames I display
+ * Frame b is displayed by rank b % N as image b / N of `images` (W * H ARGB32 each, cvx_blit_segments' pixel rule); tile t of a frame
+ * is rendered by rank t % N (as in the raybuffer gather).  The stream (src -> dst) holds the frames dst displays in frame order,
+ * each with src's pixels in row-major order.  At most 8 ranks.
+ */
+typedef struct cvx_image_plan cvx_image_plan;
+int cvx_image_plan_create(cvx_context *ctx, int frameCount, const cvx_segment_data *segments, const float *vanishingPoints, int screenWidth, int screenHeight,
+                          int rank, int worldSize, cvx_image_plan **out);
+void cvx_image_plan_destroy(cvx_image_plan *plan);
+int64_t cvx_image_plan_tile_count(const cvx_image_plan *plan);
+/* bytes of the local tile store, pixels (4 bytes each) of the send and receive streams, number of images this rank displays */
+int cvx_image_plan_sizes(const cvx_image_plan *plan, int64_t *localStoreBytes, int64_t *sendPixels, int64_t *recvPixels, int32_t *imagesDisplayed);
+int cvx_image_plan_transfer(const cvx_image_plan *plan, int peer, int64_t *sendPixel, int64_t *sendPixels, int64_t *recvPixel, int64_t *recvPixels);
+int cvx_image_plan_tile_out(const cvx_image_plan *plan, void *localStore, uint64_t *tileOut);
+int cvx_image_pack(cvx_context *ctx, const cvx_image_plan *plan, void *hipStream, const void *localStore, void *sendStream, void *images);
+int cvx_image_exchange(cvx_context *ctx, const cvx_image_plan *plan, void *comm, void *hipStream, void *sendStream, void *recvStream);
+int cvx_image_unpack(cvx_context *ctx, const cvx_image_plan *plan, void *hipStream, const void *recvStream, void *images);
+
 /* RenderManager.ClearRayBuffer, RenderManager.cs:58-92 (fills with one ARGB32
  * value, bytes A,R,G,B in memory order packed little-endian in `argb`). */
 int cvx_clear_raybuffer(cvx_context *ctx, int bufferIndex, int which, uint32_t argb);

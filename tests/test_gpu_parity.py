@@ -669,3 +669,61 @@ def test_zero_copy_sharding_emulated_on_one_gpu():
             o_td, o_lr, _ = O.draw_segments(ws, fr, W, H, clear=0, counters=False)
             _compare(f"zero-copy sharding, frame {b} on rank {r}", fr, g_td, g_lr, o_td, o_lr)
         ctx.close()
+
+
+@pytest.mark.parametrize("N", [1, 2, 3])
+def test_image_gather_emulated_on_one_gpu(N):
+    """The IMAGE gather (cvx_image_plan_* / cvx_image_pack / cvx_image_unpack): every emulated rank renders its tiles into its compact
+    local store, blits only its own pixels, the peers' pixel streams are "sent" (device copies of the plan's transfer ranges) and the
+    display rank of every frame ends up with exactly the image cvx_blit_segments makes from the whole frame on one GPU -- which in
+    turn is pinned to the numpy rule over the oracle's raybuffers."""
+    import torch
+
+    ws = scenes.load_world("proc256")
+    W, H = 320, 200
+    frames = [scenes.benchmark_frame(ws, W, H, t, 6.0) for t in (0.05, 0.3, 0.45, 0.75, 0.9, 1.1, 0.6)]
+    dev = torch.device("cuda", 0)
+    whole = gpu.Context(0, buffer_count=len(frames))
+    whole.upload_world(ws)
+    whole.set_resolution(W, H)
+    whole.draw_segments_batch(frames, 0)
+    expected = [whole.blit_segments(b) for b in range(len(frames))]
+    o_td, o_lr, _ = O.draw_segments(ws, frames[3], W, H, clear=0, counters=False)
+    assert np.array_equal(expected[3], O.blit_reference(frames[3], o_td, o_lr, W, H))
+    ranks = []
+    for r in range(N):
+        ctx = gpu.Context(0)
+        ctx.upload_world(ws)
+        ctx.set_resolution(W, H)
+        packed = ctx.pack_batch(frames)
+        plan = gpu.ImagePlan(ctx, packed, W, H, r, N)
+        store = torch.zeros(max(1, plan.local_store_bytes // 4), dtype=torch.int32, device=dev)
+        send = torch.full((max(1, plan.send_pixels),), 0x55, dtype=torch.int32, device=dev)
+        recv = torch.full((max(1, plan.recv_pixels),), 0x66, dtype=torch.int32, device=dev)
+        images = torch.full((max(1, plan.images), H, W), 0x77, dtype=torch.int32, device=dev)
+        ctx.draw_placed(packed, plan.tile_out(store.data_ptr()))
+        plan.pack(ctx, None, store.data_ptr(), send.data_ptr(), images.data_ptr())
+        ctx.synchronize()
+        ranks.append((ctx, plan, send, recv, images))
+    assert sum(p.images for _, p, _, _, _ in ranks) == len(frames)
+    # every pixel of every frame travels at most once: what the peers send == what the display ranks expect, W * H per frame in total
+    for r, (_, plan, send, _, _) in enumerate(ranks):
+        for q, (_, qplan, _, qrecv, _) in enumerate(ranks):
+            s0, sn, _, _ = plan.transfer(q)
+            _, _, r0, rn = qplan.transfer(r)
+            assert sn == rn and (q != r or sn == 0)
+            if sn:
+                qrecv[r0:r0 + rn].copy_(send[s0:s0 + sn])
+    torch.cuda.synchronize()
+    total_sent = sum(p.send_pixels for _, p, _, _, _ in ranks)
+    assert total_sent <= len(frames) * W * H and (N == 1) == (total_sent == 0)
+    for r, (ctx, plan, _, recv, images) in enumerate(ranks):
+        plan.unpack(ctx, None, recv.data_ptr(), images.data_ptr())
+        ctx.synchronize()
+        got = images.cpu().numpy().view(np.uint32)
+        for b in range(len(frames)):
+            if b % N == r:
+                assert np.array_equal(got[b // N], expected[b]), f"image gather: frame {b} on rank {r} of {N} differs in {(got[b // N] != expected[b]).sum()} pixels"
+        plan.close()
+        ctx.close()
+    whole.close()
