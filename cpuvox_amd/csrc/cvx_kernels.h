@@ -596,8 +596,9 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			// [nextFreePixelMin, nextFreePixelMax] (no exit, nothing moves), and neither end was clipped away.  So nothing of :337-421 has any
 			// effect and the four divisions are not needed.  Any lane for which this cannot be shown takes the reference's path below.
 			const auto onBound = [](f3 p, float f) { return fabsf(p.x - f * p.z) < 0.4f * fabsf(p.z); };
-			const bool windowUntouched = !COUNT && straddlesLast && straddlesNext && onBound(minClipA, frustumBoundsMin) && onBound(minClipB, frustumBoundsMin) &&
-			                             onBound(maxClipA, frustumBoundsMax) && onBound(maxClipB, frustumBoundsMax);
+			// (`&`, not `&&`: six short tests evaluated straight-line instead of a chain of divergent branches)
+			const bool windowUntouched = !COUNT && ((int)straddlesLast & (int)straddlesNext & (int)onBound(minClipA, frustumBoundsMin) & (int)onBound(minClipB, frustumBoundsMin) &
+			                                        (int)onBound(maxClipA, frustumBoundsMax) & (int)onBound(maxClipB, frustumBoundsMax)) != 0;
 			if (!CVX_USUAL(windowUntouched)) {
 				float minNext = minClipB.x / minClipB.z;
 				float minLast = minClipA.x / minClipA.z;
