@@ -158,6 +158,9 @@ __device__ __forceinline__ f3 f3_lerp(f3 a, f3 b, float t) { return { a.x + (b.x
 #define CVX_RARE(x) (x)
 #define CVX_USUAL(x) (x)
 #endif
+// non-short-circuit boolean algebra on lane masks (one s_and / s_or each; `&&` / `||` / `?:` between lane masks can become divergent branches)
+#define CVX_AND(a, b) ((a) && (b))
+#define CVX_OR(a, b) ((a) || (b))
 #define CVX_FLOAT_EPSILON 1.401298464324817e-45f /* C# float.Epsilon (denormal), DrawSegmentRayJob.cs:220 */
 
 // ---- SegmentDDAData (Assets/Code/Utils/SegmentDDAData.cs) ------------------
@@ -292,14 +295,17 @@ __device__ __forceinline__ bool clip_world_bounds(f3 pMin, f3 pMax, float fMin, 
 	const bool a2 = pMax.x > pMax.z * fMax;
 	const bool b1 = pMin.x < pMin.z * fMin;
 	const bool b2 = pMax.x < pMax.z * fMin;
-	straddles = !a1 && b1 && a2;
-	const bool needMin = a1 || b1;
-	const bool needMax = a1 ? b2 : (a2 || b2);
+	// (the flag algebra with `&` / `|` on purpose: `&&` / `?:` on lane masks are compiled into divergent branches, a handful of scalar
+	// instructions each, to compute one bit)
+	const bool n1 = !a1, n2 = !a2;
+	straddles = CVX_AND(CVX_AND(n1, b1), a2);
+	const bool needMin = CVX_OR(a1, b1);
+	const bool needMax = CVX_OR(CVX_AND(a1, b2), CVX_AND(n1, CVX_OR(a2, b2)));
 	const float lo = clip_min(pMin, pMax, a1 ? invFMax : invFMin);
-	const float hi = clip_max(pMin, pMax, (!a1 && a2) ? invFMax : invFMin);
+	const float hi = clip_max(pMin, pMax, CVX_AND(n1, a2) ? invFMax : invFMin);
 	minLerp = needMin ? lo : 0.0f;
 	maxLerp = needMax ? hi : 1.0f;
-	return a1 ? a2 : (!a2 && b1 && b2);
+	return CVX_OR(CVX_AND(a1, a2), CVX_AND(CVX_AND(n1, n2), CVX_AND(b1, b2)));
 }
 
 // ---- seen-pixel bitmask in LDS ---------------------------------------------
@@ -607,8 +613,9 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 				if (maxNext < minNext) { float t = maxNext; maxNext = minNext; minNext = t; }
 				if (maxLast < minLast) { float t = maxLast; maxLast = minLast; minLast = t; }
 				// (hw_min / hw_max: the results only go through floor / ceil and (int), which map -0 and +0 to the same 0)
-				const float camSpaceClippedMin = clippedLast ? minNext : (clippedNext ? minLast : hw_min(minLast, minNext));
-				const float camSpaceClippedMax = clippedLast ? maxNext : (clippedNext ? maxLast : hw_max(maxLast, maxNext));
+				const float bothMin = hw_min(minLast, minNext), bothMax = hw_max(maxLast, maxNext); // (computed ahead of the selects: an asm inside a select becomes a branch)
+				const float camSpaceClippedMin = clippedLast ? minNext : (clippedNext ? minLast : bothMin);
+				const float camSpaceClippedMax = clippedLast ? maxNext : (clippedNext ? maxLast : bothMax);
 
 				const int writableMinPixel = f2i_floor(camSpaceClippedMin);
 				const int writableMaxPixel = f2i(ceilf(camSpaceClippedMax));
@@ -760,7 +767,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			// the side; a load has no side effect, and the counting build counts it where the reference reads it.
 			const bool faceTop = portionTop < cameraPosYNormalized;
 			const bool faceBottom = !faceTop && portionBottom > cameraPosYNormalized;
-			const bool faceWanted = faceTop ? !(elementBoundsMax > worldBoundsMax) : (faceBottom && !(elementBoundsMin < worldBoundsMin));
+			const bool faceWanted = (faceTop && !(elementBoundsMax > worldBoundsMax)) || (faceBottom && !(elementBoundsMin < worldBoundsMin)); // (faceBottom implies !faceTop)
 			// (unconditional: both addresses are colours of this run, and a branch around one load costs more than the load)
 			const uint32_t secondaryColor = ld_color(arena, worldColumnColorsOff + (uint32_t)(faceTop ? elementColorsIndex : elementColorsIndex + elementLength - 1) * 4u);
 
