@@ -553,6 +553,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		if (__ballot(!prevDrawnShared) == 0ull) { CVX_COUNT(13); } // every lane entering could take camSpace*Last from the previous column
 		thisColumnClipped = false;
 #endif
+		bool windowClosed = false; // :399-403: the clipped column lies outside the free pixel window -> the ray is finished
 		if (curDistLast > 2.0f && frustumDirMaxWorld == CVX_FLOAT_EPSILON) { // :295-422
 			CVX_COUNT(2);
 #ifdef CVX_PROFILE_COUNTS
@@ -621,7 +622,8 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 				const int writableMaxPixel = f2i(ceilf(camSpaceClippedMax));
 
 				if (CVX_RARE((clippedLast && clippedNext) || writableMaxPixel < nextFreePixelMin || writableMinPixel > nextFreePixelMax)) {
-					return false;
+					if (COUNT) { return false; }
+					windowClosed = true; // (rendering build: no early return out of the lambda -- the element loop below gets nothing to do)
 				}
 				if (writableMinPixel > nextFreePixelMin) {
 					nextFreePixelMin = scan_up(seen, sshift, writableMinPixel, omax);
@@ -663,11 +665,11 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			float b0, t0, b1, t1;
 			runSpan(queue.x, b0, t0);
 			runSpan(queue.z, b1, t1);
-			vis0 = !(b0 > worldBoundsMax) && !(t0 < worldBoundsMin); // (a column that is drawn has at least one solid run)
-			vis1 = solidCount > 1 && !(b1 > worldBoundsMax) && !(t1 < worldBoundsMin);
+			vis0 = !windowClosed && !(b0 > worldBoundsMax) && !(t0 < worldBoundsMin); // (a column that is drawn has at least one solid run)
+			vis1 = !windowClosed && solidCount > 1 && !(b1 > worldBoundsMax) && !(t1 < worldBoundsMin);
 			ovNext = DIR > 0 ? 2 : solidCount - 1;
 		}
-		bool ovPending = !COUNT && solidCount > 2; // runs beyond the record still to be looked at
+		bool ovPending = !COUNT && !windowClosed && solidCount > 2; // runs beyond the record still to be looked at
 
 		// Element loop :441-611, realigned for SIMT: every lane first walks its own elements (cheap: decode,
 		// bounds bookkeeping, air / world-bounds culls :445-475) up to its next run that has to be projected;
@@ -752,7 +754,8 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			CVX_END(3);
 			if (COUNT ? !found : CVX_RARE(!found)) { // (rendering build: only a lane whose remaining runs beyond the record are all invisible)
 				if (COUNT && solidIndex == solidCount) { consumed = (header.z >> 16) + 1u; } // walked on to the end guard
-				break;
+				if (COUNT) { break; }
+				continue; // (rendering build: nothing is pending any more, so the loop condition ends it -- one way out of the loop instead of two)
 			}
 
 			// unlerp(0, worldMaxY, x) = (x - 0) / (worldMaxY - 0); worldMaxY is a power of two (enforced at upload), so
@@ -955,7 +958,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		// rest of the column changes no pixel.  It touches no mask word outside the window's either: a run that still passes the
 		// overlap test is clamped to rbMin = nextFreePixelMin > rbMax = nextFreePixelMax, and its word loop runs only if both lie
 		// in the same word -- which then holds pixels of the window; the horizon scans never start beyond [origMin, origMax].
-		return COUNT || nextFreePixelMin <= nextFreePixelMax;
+		return COUNT || (!windowClosed && nextFreePixelMin <= nextFreePixelMax);
 	};
 
 	// column 0: LOD check (:237-243), bounds test and fetch (World.GetVoxelColumn, World.cs:130-142)
@@ -975,13 +978,13 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		queue = ld4(arena, rec + 16u);
 	}
 
-	while (true) {
+	// ONE way out of the column loop (`alive`): every early `return` out of a divergent loop costs the structuriser a flag that is
+	// merged at every join on the way out.
+	bool alive = true;
+	while (alive) {
 		CVX_BEGIN();
 		CVX_WAITPROBE(9);
 		CVX_COUNT(1);
-		if (CVX_RARE(--guardSteps <= 0)) {
-			return;
-		}
 #ifdef CVX_EXP_EXTRA_VALU /* sensitivity experiment: N extra vector instructions per column step (results unchanged) */
 		{
 			float pad_ = curDistLast;
@@ -1066,9 +1069,9 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 				float newMax = posY + frustumDirMaxWorld * distTop;
 				float newMin = posY + frustumDirMinWorld * distBot;
 				if (CVX_RARE(newMin > worldBoundsMax || newMax < worldBoundsMin)) {
-					return; // frustum left the world entirely
-				}
-				if (columnWorldMin > newMax || columnWorldMax < newMin) {
+					alive = false; // frustum left the world entirely
+					draw = false;
+				} else if (columnWorldMin > newMax || columnWorldMax < newMin) {
 					draw = false; // this column does not overlap the writable world bounds
 				} else {
 					worldBoundsMin = newMin;
@@ -1077,11 +1080,8 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			}
 			CVX_END(1);
 			if (draw) {
-				const bool goOn = drawColumn();
+				alive = drawColumn();
 				if (COUNT) { cnt.E += consumed; }
-				if (!goOn) {
-					return;
-				}
 #ifdef CVX_PROFILE_COUNTS
 				lastColumnDrawn = sameLod;
 				lastColumnClipped = sameLod && thisColumnClipped;
@@ -1090,10 +1090,8 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			CVX_BEGIN();
 		}
 
-		// ---- next column
-		if (CVX_RARE(lastColumn || nextOutside)) {
-			return; // far clip reached / left the world: WriteSkybox
-		}
+		// ---- next column (far clip reached / left the world: WriteSkybox; the step guard never binds on valid input)
+		alive = alive && !(lastColumn || nextOutside) && --guardSteps > 0;
 #ifndef CVX_EXP_LATE_FETCH
 		header = nextHeader;
 		queue = nextQueue;
