@@ -519,6 +519,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 	// The column being processed ("cur") and the values of the DDA / LOD state that belong to it; `ray` itself
 	// already stands on the NEXT column, whose 32-byte record is in flight while this one is processed.
 	uint4 header, queue;              // record of the current column: header + its first two solid runs in walk order
+	uint4 headerB, queueB;            // ... and of the next one (the column loop alternates between the two pairs: no copies at the end of a step)
 	float curDistLast, curDistNext;   // ray.IntersectionDistances of the current column
 	int curScale;                     // voxelScale of the current column (counting build)
 	int curShift;                     // its log2 = the LOD of the current column
@@ -537,7 +538,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 
 	// Clip, element walk and pixel writes of ExecuteRay (:289-611) for the current column;
 	// false = the ray is finished (every such exit is WriteSkybox).
-	auto drawColumn = [&]() -> bool {
+	auto drawColumn = [&](const uint4 &header, const uint4 &queue) -> bool {
 		const int solidCount = (int)(header.y & 0xFFFFu);
 		CVX_BEGIN();
 		if (COUNT) { consumed = 0u; }
@@ -981,7 +982,8 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 	// ONE way out of the column loop (`alive`): every early `return` out of a divergent loop costs the structuriser a flag that is
 	// merged at every join on the way out.
 	bool alive = true;
-	while (alive) {
+	// one column step: `header` / `queue` = the column to process (already fetched), `nextHeader` / `nextQueue` receive the look-ahead
+	auto columnStep = [&](const uint4 &header, const uint4 &queue, uint4 &nextHeader, uint4 &nextQueue) {
 		CVX_BEGIN();
 		CVX_WAITPROBE(9);
 		CVX_COUNT(1);
@@ -1038,10 +1040,8 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		}
 		const bool nextOutside = (ray.px & maskX) != ray.px || (ray.pz & maskZ) != ray.pz;
 		const uint32_t rec = L.recordsOff + record_offset((ray.px & maskX) >> L.shift, (ray.pz & maskZ) >> L.shift, L.tilesZShift); // clamped into the table
-#ifndef CVX_EXP_LATE_FETCH
-		const uint4 nextHeader = ld4(arena, rec);
-		const uint4 nextQueue = ld4(arena, rec + 16u);
-#endif
+		nextHeader = ld4(arena, rec);
+		nextQueue = ld4(arena, rec + 16u);
 
 		// ---- the current column, exactly as the reference processes it
 		if (COUNT) {
@@ -1080,7 +1080,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			}
 			CVX_END(1);
 			if (draw) {
-				alive = drawColumn();
+				alive = drawColumn(header, queue);
 				if (COUNT) { cnt.E += consumed; }
 #ifdef CVX_PROFILE_COUNTS
 				lastColumnDrawn = sameLod;
@@ -1091,15 +1091,17 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		}
 
 		// ---- next column (far clip reached / left the world: WriteSkybox; the step guard never binds on valid input)
-		alive = alive && !(lastColumn || nextOutside) && --guardSteps > 0;
-#ifndef CVX_EXP_LATE_FETCH
-		header = nextHeader;
-		queue = nextQueue;
-#else
-		header = ld4(arena, rec); // straight into the registers of the column just finished: what hides the latency is the next iteration's step + address arithmetic
-		queue = ld4(arena, rec + 16u);
-#endif
+		guardSteps--;
+		alive = alive && !(lastColumn || nextOutside) && guardSteps > 0;
 		CVX_END(1);
+	};
+	// The loop alternates between two register sets for the record pair, so the look-ahead record never has to be copied into "the
+	// current one" at the end of a step (8 v_mov per step); the code of a step exists twice for it.
+	while (alive) {
+		columnStep(header, queue, headerB, queueB);
+		if (alive) {
+			columnStep(headerB, queueB, header, queue);
+		}
 	}
 }
 
