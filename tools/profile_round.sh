@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything profiles/rNN_* is made from, in one go on the GPU box: tools/profile_round.sh <tag, e.g. r02>
 # (kernel trace + stats, PMC passes, SQ stall / instruction counters of the default bench command; results under gpurun_out/<tag>/)
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
