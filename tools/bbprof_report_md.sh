@@ -1,0 +1,71 @@
+#!/bin/bash
+# usage: mk_bbprof_md.sh <bbprof dir>  -> profiles/r03_bbprof.md
+D=$1
+{
+echo "# Round 3: basic-block profile of \`render_kernel<false>\` (\`tools/bbprof.py\`, \`tools/bbprof.sh\`)"
+echo
+echo "Method: the device assembly of \`libcpuvox_gpu\` is compiled once (\`-gline-tables-only\`: same code, plus \`.loc\`); for every basic block of the kernel a variant is assembled with one"
+echo "\`s_mov_b32 vcc_lo, vcc_lo\` (counted by \`SQ_INSTS_SALU\`, changes nothing) at the top of that block and linked into its own library; one process renders the same 32 frames"
+echo "(first 32 bench poses, 1080p, 2048^3 world) once with each library under \`rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VALU\`; (count of variant b) - (count of the unmodified build) = executions of block b."
+echo "Executions x static instruction counts = the dynamic instruction budget.  Self-check (first lines of the raw report): the sum over blocks reproduces the measured \`SQ_INSTS_VALU\` exactly."
+echo
+echo '```'
+head -4 $D/bbprof.txt
+echo '```'
+echo
+echo "## Dynamic instructions per wave-step, by part of ExecuteRay"
+echo
+python3 tools/bbprof_sections.py $D
+echo
+echo "(Blocks are attributed by the highest line of \`trace_ray\`'s own body among their instructions; the four \`f3_madd\` of the Q corners (\`:289-293\`, 24 instructions per drawn column) land in the clip / run-selection rows.  Round-2 kernel, same method: 690 per step, 73 of them \`v_mov\`, ~215 scalar.)"
+echo
+echo "## \`s_waitcnt\` sites (executions per wave-step; source line of \`cvx_kernels.h\`)"
+echo
+echo "| wait | source line | per wave-step | what it waits for |"
+echo "|---|---|---|---|"
+python3 - $D <<'PY'
+import json,re,collections,sys,os
+d=sys.argv[1]
+m=json.load(open(d+'/blocks.json')); p=json.load(open(d+'/profile.json'))
+ex={int(k):v for k,v in p['executions'].items()}
+lines=open(d+'/device.s').read().split('\n')
+heads=[]
+for i,b in enumerate(m):
+    a=b['line']; z=m[i+1]['line'] if i+1<len(m) else len(lines)
+    if sum(1 for l in lines[a:z] if 'global_load_dwordx4' in l)>=2 and ex.get(b['block'],0)>1000: heads.append((i,ex[b['block']]))
+half=len(heads)//2; split=heads[half][0]-3
+sA=sum(e for i,e in heads if i<split); sB=sum(e for i,e in heads if i>=split)
+lo,hi,S=(0,split,sA) if sA>=sB else (split,len(m),sB)
+src=open(os.path.join(os.path.dirname(os.path.abspath(d)),'..','cpuvox_amd','csrc','cvx_kernels.h')).read().split('\n') if False else None
+rows=collections.Counter()
+for i in range(lo,hi):
+    b=m[i]; a=b['line']; z=m[i+1]['line'] if i+1<len(m) else len(lines)
+    e=ex.get(b['block'],0); loc=None
+    for l in lines[a:z]:
+        s=l.strip()
+        mm=re.match(r"\.loc\s+\d+\s+(\d+)",s)
+        if mm: loc=int(mm.group(1)); continue
+        if s.startswith('s_waitcnt'): rows[(s.split(None,1)[1],loc)]+=e
+def what(w,loc):
+    if loc is None or loc==0: return "compiler-placed (join)"
+    if loc in (66,67,68) or 1025<=loc<=1075 or 250<=loc<=270: return "record of the column now being processed (its two loads were issued one step earlier as the look-ahead)" if 'vmcnt' in w else ""
+    if 317<=loc<=360: return "LDS mask word of a horizon scan"
+    if 840<=loc<=890 and 'lgkm' in w: return "LDS mask word of the side pixel loop"
+    if 930<=loc<=960 and 'lgkm' in w: return "LDS mask word of the face pixel loop"
+    if loc in (48,50): return "colour loads ahead of the pixel stores"
+    if 640<=loc<=760: return "record words of the current column / run-list entry (columns with > 2 solid runs)"
+    if 760<=loc<=800: return "face colour / record words before the side projection"
+    return ""
+for (w,loc),e in sorted(rows.items(), key=lambda kv:-kv[1]):
+    if e/S<0.01: continue
+    print(f"| `{w}` | {loc} | {e/S:.3f} | {what(w,loc)} |")
+print()
+print(f"Total: {sum(rows.values())/S:.2f} `s_waitcnt` per wave-step.")
+PY
+echo
+echo "## The 40 heaviest blocks (raw report: block, asm line, source lines, static valu / salu / branch / memory, executions, dynamic instructions)"
+echo
+echo '```'
+sed -n 5,45p $D/bbprof.txt
+echo '```'
+} > profiles/r03_bbprof.md
