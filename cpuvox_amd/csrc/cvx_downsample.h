@@ -258,6 +258,216 @@ __global__ __launch_bounds__(256) void downsample_kernel(DownsampleParams P, Dow
 	}
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Low levels (2 x 2 or 4 x 4 source columns per target column): ONE THREAD per target column.  A workgroup per target
+// column (above) leaves 60 of 64 lanes idle at LOD 1, and LOD 1 has a million target columns at 2048^2.  Here a thread
+// walks its source columns top-down with one cursor each, bucket by bucket of the target (Y >> extraLods): sums and count of
+// the voxels that fall into the bucket, the alpha of the first one in the reference's insertion order (source column s =
+// ix * steps + iz ascending, runs top-down, voxels of a run bottom-up: World.cs:85-94,101-127), then the run-length
+// encoding of RLEColumnBuilder.ToFinalColumn (WordBuilder.cs:181-268) as a scalar state machine.  Same two passes around the
+// same scan, byte-identical output (tests: device blob == host blob).
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool WRITE, int E>
+__global__ __launch_bounds__(64) void downsample_thread_kernel(DownsampleParams P, DownsampleOut O)
+{
+	constexpr int steps = 1 << E, S = steps * steps;
+	const int k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= P.targetColumns) {
+		return;
+	}
+	const int targetLod = P.srcLod + E;
+	const int step = 1 << targetLod, stepSize = 1 << P.srcLod;
+	const int xStart = (k / P.targetColumnsZ) * step, zStart = (k % P.targetColumnsZ) * step;
+	const int srcHeight = P.dimY >> P.srcLod;
+	const int topY = (P.dimY >> targetLod) - 1;
+
+	// one cursor per source column: the run it stands on (solid runs only; air is skipped when advancing)
+	uint32_t nextRun[S];   // index (into srcElements) of the next run word to read
+	int runsLeft[S];       // run words not yet read
+	int bound[S];          // elementBoundsX: bottom of the last run read = top (exclusive) of what is left
+	int curLo[S], curLen[S]; // current solid run: source Ys [curLo, curLo + curLen - 1]; curLen == 0: none left
+	uint32_t curColour[S];   // index (into srcElements) of the column's colours (behind its end guard)
+	int colourIndexOfRun[S]; // ColorsIndex of the current run (its colours are stored top -> bottom)
+	int spanLo = 0x7FFFFFFF, spanHi = -1;
+#pragma unroll
+	for (int s = 0; s < S; s++) {
+		const int x = xStart + (s / steps) * stepSize, z = zStart + (s % steps) * stepSize;
+		const uint32_t *h = P.srcHeaders + 3 * (size_t)((x >> P.srcLod) * P.srcMulX + (z >> P.srcLod));
+		const uint32_t offset = h[0];
+		const int runCount = (int)(h[1] & 0xFFFFu);
+		// span of the occupied buckets (as the workgroup kernel: from the runs, not from the headers' WorldMin / WorldMax)
+		int b = srcHeight;
+		for (int run = 0; run < runCount; run++) {
+			const uint32_t raw = P.srcElements[offset + 1u + (uint32_t)run];
+			const int length = (int)(int16_t)(raw >> 16);
+			b -= length;
+			if ((int16_t)(raw & 0xFFFFu) >= 0) {
+				spanHi = max(spanHi, (b + length - 1) >> E);
+				spanLo = min(spanLo, b >> E);
+			}
+		}
+		nextRun[s] = offset + 1u;
+		runsLeft[s] = runCount;
+		bound[s] = srcHeight;
+		curLen[s] = 0;
+		curLo[s] = 0;
+		curColour[s] = offset + (uint32_t)runCount + 2u; // colours of the column start behind the end guard
+	}
+	if (spanHi < 0) { // every source column is empty
+		if (!WRITE) {
+			O.alloc[k] = 0u;
+			O.runCounts[k] = 0u;
+		}
+		return;
+	}
+	if (spanHi > topY) { spanHi = topY; }
+
+	uint32_t elemBase = 0, colourBase = 0;
+	if (WRITE) {
+		if (O.runCounts[k] == 0u) {
+			return; // empty column: the header stays zero
+		}
+		elemBase = O.alloc[k];
+		colourBase = elemBase + O.runCounts[k] + 2u;
+	}
+	int runLen = 0, runColorsIndex = 0, runs = 0, solid = 0;
+	bool runSolid = false;
+	int highest = -1, lowest = 0;
+	auto flushRun = [&]() {
+		if (runLen > 0) {
+			if (WRITE) {
+				O.elements[elemBase + 1u + (uint32_t)runs] = (uint32_t)(runSolid ? (runColorsIndex & 0xFFFF) : 0xFFFF) | ((uint32_t)runLen << 16);
+			}
+			runs++;
+			runLen = 0;
+		}
+	};
+	if (spanHi < topY) { // the air above the highest voxel
+		runSolid = false;
+		runLen = topY - spanHi;
+	}
+	const uint32_t *colourPool = P.srcElements;
+	// every cursor on its first solid run
+	auto fetchRun = [&](int s) { // next solid run of source s (air only moves the bound); curLen[s] stays 0 when there is none
+		while (curLen[s] == 0 && runsLeft[s] > 0) {
+			const uint32_t raw = P.srcElements[nextRun[s]];
+			nextRun[s]++;
+			runsLeft[s]--;
+			const int length = (int)(int16_t)(raw >> 16);
+			const int colorsIndex = (int)(int16_t)(raw & 0xFFFFu);
+			bound[s] -= length;
+			if (colorsIndex >= 0) {
+				curLo[s] = bound[s];
+				curLen[s] = length;
+				colourIndexOfRun[s] = colorsIndex;
+			}
+		}
+	};
+#pragma unroll
+	for (int s = 0; s < S; s++) { fetchRun(s); }
+	int yPrev = spanHi + 1; // the bucket above the next one to emit
+	for (int guard = spanHi - spanLo + 2; guard > 0; guard--) { // (every pass emits a lower bucket; the bound only makes termination independent of the data)
+		// the highest bucket that still holds a voxel: buckets between it and the previous one are air (a column with a floating layer has
+		// hundreds of them -- they are not visited one by one)
+		int y = -1;
+#pragma unroll
+		for (int s = 0; s < S; s++) {
+			if (curLen[s] > 0) { y = max(y, (curLo[s] + curLen[s] - 1) >> E); }
+		}
+		if (y < 0) {
+			break;
+		}
+		if (y > topY) { y = topY; } // (cannot happen for a valid source: its height is srcHeight)
+		const int gap = yPrev - 1 - y;
+		if (gap > 0) { // `gap` air buckets, as the per-bucket rule below would treat them
+			if (runLen > 0 && runSolid) { flushRun(); }
+			if (runLen == 0) { runSolid = false; runColorsIndex = solid; }
+			runLen += gap;
+		}
+		yPrev = y;
+		const int bLo = y << E, bHi = bLo + steps - 1; // source Ys of this bucket
+		uint32_t sumR = 0u, sumG = 0u, sumB = 0u, n = 0u, firstAlpha = 0u;
+#pragma unroll
+		for (int s = 0; s < S; s++) {
+			while (curLen[s] > 0) {
+				const int lo = curLo[s], hi = lo + curLen[s] - 1;
+				if (hi < bLo) {
+					break; // the run lies below this bucket: nothing more from this source here
+				}
+				// voxels of the run inside the bucket: Ys [max(lo, bLo), min(hi, bHi)], visited bottom-up like the reference
+				const int yFrom = lo > bLo ? lo : bLo, yTo = hi < bHi ? hi : bHi;
+				for (int Y = yFrom; Y <= yTo; Y++) {
+					const int i = Y - lo;
+					const uint32_t c = colourPool[curColour[s] + (uint32_t)(colourIndexOfRun[s] + curLen[s] - i - 1)]; // bytes a, r, g, b
+					if (n == 0u) { firstAlpha = c & 0xFFu; }
+					sumR += (c >> 8) & 0xFFu;
+					sumG += (c >> 16) & 0xFFu;
+					sumB += c >> 24;
+					n++;
+				}
+				if (lo >= bLo) {
+					curLen[s] = 0; // consumed: the next run of this source may reach into the same bucket
+					fetchRun(s);
+					continue;
+				}
+				// the run goes on below this bucket: keep its lower part [lo, bLo - 1] (its colours are stored top -> bottom, so the
+				// colour of the part's top voxel is further down the run's colour list by the number of voxels consumed)
+				colourIndexOfRun[s] += curLen[s] - (bLo - lo);
+				curLen[s] = bLo - lo;
+				break;
+			}
+		}
+		// (n > 0: the bucket was chosen because a run reaches into it)
+		if (highest < 0) { highest = y; }
+		lowest = y;
+		if (runLen > 0 && !runSolid) {
+			flushRun();
+		}
+		if (runLen == 0) {
+			runSolid = true;
+			runColorsIndex = solid;
+		}
+		runLen++;
+		if (WRITE) {
+			O.elements[colourBase + (uint32_t)solid] = firstAlpha | ((sumR / n) << 8) | ((sumG / n) << 16) | ((sumB / n) << 24);
+		}
+		solid++;
+	}
+	if (spanLo > 0) { // the air below the lowest voxel
+		if (runLen > 0 && runSolid) {
+			flushRun();
+		}
+		runSolid = false;
+		runLen += spanLo;
+	}
+	flushRun();
+
+	if (solid == 0) {
+		if (!WRITE) {
+			O.alloc[k] = 0u;
+			O.runCounts[k] = 0u;
+		}
+		return;
+	}
+	if (!WRITE) {
+		if (runs > 65535) {
+			*O.error = 1;
+		}
+		O.alloc[k] = (uint32_t)(runs + solid + 2);
+		O.runCounts[k] = (uint32_t)runs;
+		atomicAdd(O.voxelCount, (unsigned long long)solid);
+	} else {
+		const uint32_t voxelScale = 1u << targetLod;
+		const uint32_t worldMin = ((uint32_t)lowest * voxelScale) & 0xFFFFu;        // (ushort) casts of World.cs:231-232
+		const uint32_t worldMax = ((uint32_t)(highest + 1) * voxelScale) & 0xFFFFu;
+		O.headers[3 * (size_t)k + 0] = elemBase;
+		O.headers[3 * (size_t)k + 1] = (uint32_t)runs | (worldMin << 16);
+		O.headers[3 * (size_t)k + 2] = worldMax;
+		O.elements[elemBase] = 0u;                      // element guards, World.cs:205-209
+		O.elements[elemBase + 1u + (uint32_t)runs] = 0u;
+	}
+}
+
 // Exclusive prefix sum of n counts in place (one workgroup; n is a few million at most); *total receives the sum.
 __global__ __launch_bounds__(1024) void exclusive_scan_kernel(uint32_t *values, int n, unsigned long long *total)
 {
