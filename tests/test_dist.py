@@ -203,3 +203,87 @@ def test_bench_self_launches_one_process_per_gpu():
 
     if not torch.cuda.is_available():
         assert r.returncode != 0 and "needs a GPU" in r.stderr
+
+
+def _rccl_worker(rank, world_size, port, gather, result_queue):
+    """One rank of the real thing: its own GPU, cvx_comm_create over the id broadcast by gloo, cvx_exchange / cvx_image_exchange on RCCL."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    from cpuvox_amd import gpu
+
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        torch.cuda.set_device(rank)
+        dev = torch.device("cuda", rank)
+        ws = scenes.load_world("proc256")
+        frames = [scenes.benchmark_frame(ws, W, H, t, 6.0) for t in TIMES]
+        ctx = gpu.Context(rank)
+        ctx.upload_world(ws)
+        ctx.set_resolution(W, H)
+        packed = ctx.pack_batch(frames)
+        uid = [gpu.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        comm = gpu.comm_create(ctx, uid[0], rank, world_size, timeout_s=120.0)
+        ok = True
+        if gather == "raybuffer":
+            plan = gpu.NativeShardPlan(packed, W, H, rank, world_size)
+            pyplan = cdist.ShardPlan(frames, W, H, rank, world_size)
+            send = torch.zeros((max(1, plan.send_total), 64), dtype=torch.int32, device=dev)
+            disp = torch.zeros((max(1, plan.disp_total), 64), dtype=torch.int32, device=dev)
+            ctx.draw_placed(packed, plan.tile_out(send.data_ptr(), disp.data_ptr()))
+            plan.exchange(ctx, comm, None, send.data_ptr(), disp.data_ptr())
+            ctx.synchronize()
+            for b, fr in enumerate(frames):
+                if b % world_size != rank:
+                    continue
+                g_td, g_lr = pyplan.assemble(disp, b, [s.RayCount for s in fr.segments], W, H)
+                o_td, o_lr, _ = O.draw_segments(ws, fr, W, H, clear=0, counters=False, threads=2)
+                n_td, n_lr = scenes.used_rows(fr)
+                ok = ok and bool((g_td[:n_td] == o_td[:n_td]).all() and (g_lr[:n_lr] == o_lr[:n_lr]).all())
+            sent = plan.send_total
+        else:
+            plan = gpu.ImagePlan(ctx, packed, W, H, rank, world_size)
+            store = torch.zeros(max(1, plan.local_store_bytes // 4), dtype=torch.int32, device=dev)
+            send = torch.zeros(max(1, plan.send_pixels), dtype=torch.int32, device=dev)
+            recv = torch.zeros(max(1, plan.recv_pixels), dtype=torch.int32, device=dev)
+            images = torch.zeros((max(1, plan.images), H, W), dtype=torch.int32, device=dev)
+            ctx.draw_placed(packed, plan.tile_out(store.data_ptr()))
+            plan.pack(ctx, None, store.data_ptr(), send.data_ptr(), images.data_ptr())
+            plan.exchange(ctx, comm, None, send.data_ptr(), recv.data_ptr())
+            plan.unpack(ctx, None, recv.data_ptr(), images.data_ptr())
+            ctx.synchronize()
+            got = images.cpu().numpy().view(np.uint32)
+            for b, fr in enumerate(frames):
+                if b % world_size != rank:
+                    continue
+                o_td, o_lr, _ = O.draw_segments(ws, fr, W, H, clear=0, counters=False, threads=2)
+                ok = ok and bool((got[b // world_size] == O.blit_reference(fr, o_td, o_lr, W, H)).all())
+            sent = plan.send_pixels
+        gpu.comm_destroy(comm)
+        ctx.close()
+        result_queue.put((rank, ok, int(sent)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gather", ["raybuffer", "image"])
+def test_exchange_on_real_rccl_two_gpus(gather):
+    """cvx_comm_create + cvx_exchange / cvx_image_exchange with a real peer (ncclCommInitRank, grouped ncclSend / ncclRecv over xGMI),
+    two ranks on two GPUs, frames against the oracle.  Skipped on hosts with fewer than two devices (the one-GPU boxes of this pool)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, 2, port, gather, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    results.sort()
+    assert all(ok for _, ok, _ in results), results
+    assert results[0][2] > 0 and results[1][2] > 0
