@@ -666,6 +666,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			float b0, t0, b1, t1;
 			runSpan(queue.x, b0, t0);
 			runSpan(queue.z, b1, t1);
+			asm volatile("" : "+v"(b0), "+v"(t0), "+v"(b1), "+v"(t1)); // (all four computed here: otherwise the second compare of each pair is sunk into a divergent branch of its own)
 			vis0 = !windowClosed && !(b0 > worldBoundsMax) && !(t0 < worldBoundsMin); // (a column that is drawn has at least one solid run)
 			vis1 = !windowClosed && solidCount > 1 && !(b1 > worldBoundsMax) && !(t1 < worldBoundsMin);
 			ovNext = DIR > 0 ? 2 : solidCount - 1;
