@@ -367,19 +367,18 @@ __device__ __forceinline__ uint32_t range_mask(int w, int lo, int hi)
 __device__ __forceinline__ void reduce_pixel_horizon(const uint32_t *seen, int sshift, int omin, int omax, int &rbMin, int &rbMax, int &nfMin, int &nfMax,
                                                      float &frustumBoundsMin, float &frustumBoundsMax)
 {
-	if (rbMin <= nfMin) {
-		rbMin = nfMin;
-		if (rbMax >= nfMin) {
-			nfMin = scan_up(seen, sshift, rbMax + 1, omax);
-			frustumBoundsMin = (float)nfMin - 0.501f;
-		}
+	// (each clamp as a max / min and ONE divergent region per side instead of two nested ones)
+	const bool raiseMin = ((int)(rbMin <= nfMin) & (int)(rbMax >= nfMin)) != 0;
+	rbMin = max(rbMin, nfMin);
+	if (raiseMin) {
+		nfMin = scan_up(seen, sshift, rbMax + 1, omax);
+		frustumBoundsMin = (float)nfMin - 0.501f;
 	}
-	if (rbMax >= nfMax) {
-		rbMax = nfMax;
-		if (rbMin <= nfMax) {
-			nfMax = scan_down(seen, sshift, rbMin - 1, omin);
-			frustumBoundsMax = (float)nfMax + 0.501f;
-		}
+	const bool lowerMax = ((int)(rbMax >= nfMax) & (int)(rbMin <= nfMax)) != 0;
+	rbMax = min(rbMax, nfMax);
+	if (lowerMax) {
+		nfMax = scan_down(seen, sshift, rbMin - 1, omin);
+		frustumBoundsMax = (float)nfMax + 0.501f;
 	}
 }
 
@@ -666,9 +665,9 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			float b0, t0, b1, t1;
 			runSpan(queue.x, b0, t0);
 			runSpan(queue.z, b1, t1);
-			asm volatile("" : "+v"(b0), "+v"(t0), "+v"(b1), "+v"(t1)); // (all four computed here: otherwise the second compare of each pair is sunk into a divergent branch of its own)
-			vis0 = !windowClosed && !(b0 > worldBoundsMax) && !(t0 < worldBoundsMin); // (a column that is drawn has at least one solid run)
-			vis1 = !windowClosed && solidCount > 1 && !(b1 > worldBoundsMax) && !(t1 < worldBoundsMin);
+			const bool in0 = ((int)!(b0 > worldBoundsMax) & (int)!(t0 < worldBoundsMin)) != 0, in1 = ((int)(solidCount > 1) & (int)!(b1 > worldBoundsMax) & (int)!(t1 < worldBoundsMin)) != 0;
+			vis0 = !windowClosed && in0; // (a column that is drawn has at least one solid run)
+			vis1 = !windowClosed && in1;
 			ovNext = DIR > 0 ? 2 : solidCount - 1;
 		}
 		bool ovPending = !COUNT && !windowClosed && solidCount > 2; // runs beyond the record still to be looked at
@@ -771,8 +770,9 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			// last for a bottom face, :553,560) is in flight while the side is projected and drawn.  The reference reads it after
 			// the side; a load has no side effect, and the counting build counts it where the reference reads it.
 			const bool faceTop = portionTop < cameraPosYNormalized;
-			const bool faceBottom = !faceTop && portionBottom > cameraPosYNormalized;
-			const bool faceWanted = (faceTop && !(elementBoundsMax > worldBoundsMax)) || (faceBottom && !(elementBoundsMin < worldBoundsMin)); // (faceBottom implies !faceTop)
+			// (`&` / `|`: four compares and three scalar ands / ors, straight-line; the short-circuit forms are compiled into three nested divergent regions)
+			const bool faceBottom = ((int)!faceTop & (int)(portionBottom > cameraPosYNormalized)) != 0;
+			const bool faceWanted = (((int)faceTop & (int)!(elementBoundsMax > worldBoundsMax)) | ((int)faceBottom & (int)!(elementBoundsMin < worldBoundsMin))) != 0; // (faceBottom implies !faceTop)
 			// (unconditional: both addresses are colours of this run, and a branch around one load costs more than the load)
 			const uint32_t secondaryColor = ld_color(arena, worldColumnColorsOff + (uint32_t)(faceTop ? elementColorsIndex : elementColorsIndex + elementLength - 1) * 4u);
 
@@ -787,20 +787,22 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 				float uB = 0.0f;
 				bool visible = true; // ClipHomogeneousCameraSpaceLine with u, CameraData.cs:141-157
 				bool nearClipped = false;
-				if (CVX_RARE(camSpaceFrontBottom.y <= 0.0f)) {
-					if (camSpaceFrontTop.y <= 0.0f) {
-						visible = false;
+				if (CVX_RARE(((int)(camSpaceFrontBottom.y <= 0.0f) | (int)(camSpaceFrontTop.y <= 0.0f)) != 0)) { // (one test on the common path)
+					if (camSpaceFrontBottom.y <= 0.0f) {
+						if (camSpaceFrontTop.y <= 0.0f) {
+							visible = false;
+						} else {
+							float v = camSpaceFrontTop.y / (camSpaceFrontTop.y - camSpaceFrontBottom.y);
+							camSpaceFrontBottom = f3_lerp(camSpaceFrontTop, camSpaceFrontBottom, v);
+							uA = m_lerp(uB, uA, v);
+							nearClipped = true;
+						}
 					} else {
-						float v = camSpaceFrontTop.y / (camSpaceFrontTop.y - camSpaceFrontBottom.y);
-						camSpaceFrontBottom = f3_lerp(camSpaceFrontTop, camSpaceFrontBottom, v);
-						uA = m_lerp(uB, uA, v);
+						float v = camSpaceFrontBottom.y / (camSpaceFrontBottom.y - camSpaceFrontTop.y);
+						camSpaceFrontTop = f3_lerp(camSpaceFrontBottom, camSpaceFrontTop, v);
+						uB = m_lerp(uA, uB, v);
 						nearClipped = true;
 					}
-				} else if (CVX_RARE(camSpaceFrontTop.y <= 0.0f)) {
-					float v = camSpaceFrontBottom.y / (camSpaceFrontBottom.y - camSpaceFrontTop.y);
-					camSpaceFrontTop = f3_lerp(camSpaceFrontBottom, camSpaceFrontTop, v);
-					uB = m_lerp(uA, uB, v);
-					nearClipped = true;
 				}
 				haveFrontQuotients = visible;
 				if (CVX_USUAL(visible)) {
@@ -835,7 +837,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 					}
 					int rbMin = f2i(rintf(boundsX));
 					int rbMax = f2i(rintf(boundsY));
-					if (CVX_USUAL(rbMax >= nextFreePixelMin && rbMin <= nextFreePixelMax)) {
+					if (CVX_USUAL(((int)(rbMax >= nextFreePixelMin) & (int)(rbMin <= nextFreePixelMax)) != 0)) {
 						CVX_COUNT(10);
 						reduce_pixel_horizon(seen, sshift, omin, omax, rbMin, rbMax, nextFreePixelMin, nextFreePixelMax, frustumBoundsMin, frustumBoundsMax);
 						CVX_END(4);
@@ -902,17 +904,19 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			CVX_COUNT(6);
 			bool visible = true; // ClipHomogeneousCameraSpaceLine, CameraData.cs:124-138
 			bool secBKept = haveFrontQuotients; // secB is still the front end the side block projected
-			if (CVX_RARE(secA.y <= 0.0f)) {
-				if (secB.y <= 0.0f) {
-					visible = false;
+			if (CVX_RARE(((int)(secA.y <= 0.0f) | (int)(secB.y <= 0.0f)) != 0)) { // (one test on the common path)
+				if (secA.y <= 0.0f) {
+					if (secB.y <= 0.0f) {
+						visible = false;
+					} else {
+						float v = secB.y / (secB.y - secA.y);
+						secA = f3_lerp(secB, secA, v);
+					}
 				} else {
-					float v = secB.y / (secB.y - secA.y);
-					secA = f3_lerp(secB, secA, v);
+					float v = secA.y / (secA.y - secB.y);
+					secB = f3_lerp(secA, secB, v);
+					secBKept = false;
 				}
-			} else if (CVX_RARE(secB.y <= 0.0f)) {
-				float v = secA.y / (secA.y - secB.y);
-				secB = f3_lerp(secA, secB, v);
-				secBKept = false;
 			}
 			if (CVX_USUAL(visible)) {
 				CVX_COUNT(11);
@@ -926,7 +930,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 				if (rbMin > rbMax) {
 					int t = rbMin; rbMin = rbMax; rbMax = t;
 				}
-				if (CVX_USUAL(rbMax >= nextFreePixelMin && rbMin <= nextFreePixelMax)) {
+				if (CVX_USUAL(((int)(rbMax >= nextFreePixelMin) & (int)(rbMin <= nextFreePixelMax)) != 0)) {
 					CVX_COUNT(12);
 					reduce_pixel_horizon(seen, sshift, omin, omax, rbMin, rbMax, nextFreePixelMin, nextFreePixelMax, frustumBoundsMin, frustumBoundsMax);
 					CVX_END(6);
@@ -1062,22 +1066,21 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			bool draw = true;
 			worldBoundsMin = 0.0f;
 			worldBoundsMax = worldMaxY;
-			if (frustumDirMaxWorld != CVX_FLOAT_EPSILON) { // :261-281
+			{ // :261-281, straight-line: the tests as flags (`&` / `|`: no nested divergent regions), the bounds as selects
+				const bool cull = frustumDirMaxWorld != CVX_FLOAT_EPSILON;
 				const float columnWorldMin = (float)(header.y >> 16);
 				const float columnWorldMax = (float)(header.z & 0xFFFFu);
-				float distTop = frustumDirMaxWorld > 0.0f ? curDistNext : curDistLast;
-				float distBot = frustumDirMinWorld < 0.0f ? curDistNext : curDistLast;
-				float newMax = posY + frustumDirMaxWorld * distTop;
-				float newMin = posY + frustumDirMinWorld * distBot;
-				if (CVX_RARE(newMin > worldBoundsMax || newMax < worldBoundsMin)) {
-					alive = false; // frustum left the world entirely
-					draw = false;
-				} else if (columnWorldMin > newMax || columnWorldMax < newMin) {
-					draw = false; // this column does not overlap the writable world bounds
-				} else {
-					worldBoundsMin = newMin;
-					worldBoundsMax = newMax;
-				}
+				const float distTop = frustumDirMaxWorld > 0.0f ? curDistNext : curDistLast;
+				const float distBot = frustumDirMinWorld < 0.0f ? curDistNext : curDistLast;
+				const float newMax = posY + frustumDirMaxWorld * distTop;
+				const float newMin = posY + frustumDirMinWorld * distBot;
+				const bool leftWorld = ((int)cull & ((int)(newMin > worldBoundsMax) | (int)(newMax < worldBoundsMin))) != 0; // frustum left the world entirely
+				const bool noOverlap = ((int)cull & ((int)(columnWorldMin > newMax) | (int)(columnWorldMax < newMin))) != 0; // this column does not overlap the writable world bounds
+				const bool narrowed = ((int)cull & (int)!leftWorld & (int)!noOverlap) != 0;
+				alive = !leftWorld;
+				draw = (((int)leftWorld | (int)noOverlap)) == 0;
+				worldBoundsMin = narrowed ? newMin : worldBoundsMin;
+				worldBoundsMax = narrowed ? newMax : worldBoundsMax;
 			}
 			CVX_END(1);
 			if (draw) {
