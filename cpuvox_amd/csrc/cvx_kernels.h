@@ -702,19 +702,29 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 				if (DIR < 0 && CVX_RARE(ovPending)) {
 					scanOverflow();
 				}
-				if (!found) {
-					const bool take0 = DIR > 0 ? vis0 : (vis0 && !vis1);
-					const bool take1 = DIR > 0 ? (vis1 && !vis0) : vis1;
-					if (take0 || take1) {
-						found = true;
-						const uint32_t w0 = take0 ? queue.x : queue.z;
-						const uint32_t w1 = take0 ? queue.y : queue.w;
+				{ // the next visible run of the record, as selects (no divergent region: a lane without one keeps what it has)
+					const bool free = !found; // (top-down: always -- the scan of the runs beyond the record comes after this)
+					const bool take0 = ((int)free & (int)(DIR > 0 ? vis0 : (vis0 && !vis1))) != 0;
+					const bool take1 = ((int)free & (int)(DIR > 0 ? (vis1 && !vis0) : vis1)) != 0;
+					const bool take = ((int)take0 | (int)take1) != 0;
+					const uint32_t w0 = take0 ? queue.x : queue.z;
+					const uint32_t w1 = take0 ? queue.y : queue.w;
+					float spanMin, spanMax;
+					runSpan(w0, spanMin, spanMax);
+					if (DIR > 0) { // (nothing found yet: a lane that takes nothing here either scans on below or leaves the loop)
 						elementLength = (int)(w0 >> 16);
 						elementColorsIndex = (int)(w1 & 0xFFFFu);
-						runSpan(w0, elementBoundsMin, elementBoundsMax);
-						vis0 = vis0 && !take0;
-						vis1 = vis1 && !take1;
+						elementBoundsMin = spanMin;
+						elementBoundsMax = spanMax;
+					} else {
+						elementLength = take ? (int)(w0 >> 16) : elementLength;
+						elementColorsIndex = take ? (int)(w1 & 0xFFFFu) : elementColorsIndex;
+						elementBoundsMin = take ? spanMin : elementBoundsMin;
+						elementBoundsMax = take ? spanMax : elementBoundsMax;
 					}
+					found = ((int)found | (int)take) != 0;
+					vis0 = vis0 && !take0;
+					vis1 = vis1 && !take1;
 				}
 				if (DIR > 0 && !found && CVX_RARE(ovPending)) {
 					scanOverflow();
@@ -805,13 +815,14 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 					}
 				}
 				haveFrontQuotients = visible;
-				if (CVX_USUAL(visible)) {
+				{ // (a side entirely behind the near plane runs through the projection with whatever it holds and fails the overlap test below: no branch of its own)
 					CVX_COUNT(9);
 					// uvA = (1, uA) / bottom.z, uvB = (1, uB) / top.z (:490-493) and ProjectClippedToScreen (CameraData.cs:160) of both ends:
 					// three numerators per denominator.  Ordinary case (nothing near-clipped, so uA = the run length in [1, 65535] and
 					// uB = 0, and all of x, z of both ends within [2^-30, 2^30]): one refined reciprocal per end (see quot_safe).
 					float uvAx, uvAy, uvBx, uvBy;
-					if (CVX_USUAL(!nearClipped && div_safe(camSpaceFrontBottom.z) && div_safe(camSpaceFrontTop.z) && div_safe(camSpaceFrontBottom.x) && div_safe(camSpaceFrontTop.x))) {
+					// (computed by every lane, and replaced behind ONE rare branch where the operands are not in that range: an if / else costs two)
+					{
 						const Recip rb = recip_safe(camSpaceFrontBottom.z), rt = recip_safe(camSpaceFrontTop.z);
 						uvAx = quot_safe(1.0f, rb);
 						uvAy = quot_safe(uA, rb);
@@ -819,7 +830,8 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 						uvBx = quot_safe(1.0f, rt);
 						uvBy = __int_as_float(__float_as_int(camSpaceFrontTop.z) & (int)0x80000000); // +0 / z: a zero with the sign of z
 						frontTopQuotient = quot_safe(camSpaceFrontTop.x, rt);
-					} else {
+					}
+					if (CVX_RARE(!(!nearClipped && div_safe(camSpaceFrontBottom.z) && div_safe(camSpaceFrontTop.z) && div_safe(camSpaceFrontBottom.x) && div_safe(camSpaceFrontTop.x)))) {
 						uvAx = 1.0f / camSpaceFrontBottom.z;
 						uvAy = uA / camSpaceFrontBottom.z;
 						uvBx = 1.0f / camSpaceFrontTop.z;
@@ -837,7 +849,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 					}
 					int rbMin = f2i(rintf(boundsX));
 					int rbMax = f2i(rintf(boundsY));
-					if (CVX_USUAL(((int)(rbMax >= nextFreePixelMin) & (int)(rbMin <= nextFreePixelMax)) != 0)) {
+					if (CVX_USUAL(((int)visible & (int)(rbMax >= nextFreePixelMin) & (int)(rbMin <= nextFreePixelMax)) != 0)) {
 						CVX_COUNT(10);
 						reduce_pixel_horizon(seen, sshift, omin, omax, rbMin, rbMax, nextFreePixelMin, nextFreePixelMax, frustumBoundsMin, frustumBoundsMax);
 						CVX_END(4);
@@ -893,18 +905,17 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 
 			// top / bottom of the run, :544-610
 			CVX_END(4); // (remainder of) the side block
-			if (CVX_RARE(!faceWanted)) {
-				continue; // seen from the side, or the face lies outside the world bounds (:551,558,564)
-			}
-			if (COUNT) { cnt.C++; }
+			// (a run seen from the side, or whose face lies outside the world bounds (:551,558,564), goes through the face block as "not visible": the
+			// block is straight-line up to the overlap test, and some lane of the wave needs it anyway)
+			if (COUNT && faceWanted) { cnt.C++; }
 			f3 secA = f3_lerp(camSpaceMinNext, camSpaceMaxNext, faceTop ? portionTop : portionBottom);
 			f3 secB = faceTop ? camSpaceFrontTop : camSpaceFrontBottom;
 			float secBQuotient = sharedQuotient;
 
 			CVX_COUNT(6);
-			bool visible = true; // ClipHomogeneousCameraSpaceLine, CameraData.cs:124-138
-			bool secBKept = haveFrontQuotients; // secB is still the front end the side block projected
-			if (CVX_RARE(((int)(secA.y <= 0.0f) | (int)(secB.y <= 0.0f)) != 0)) { // (one test on the common path)
+			bool visible = faceWanted; // ClipHomogeneousCameraSpaceLine, CameraData.cs:124-138
+			// (ONE test on the common path: an end behind the near plane, or secB no longer the front end the side block projected)
+			if (CVX_RARE(((int)(secA.y <= 0.0f) | (int)(secB.y <= 0.0f) | (int)!haveFrontQuotients) != 0)) {
 				if (secA.y <= 0.0f) {
 					if (secB.y <= 0.0f) {
 						visible = false;
@@ -912,25 +923,22 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 						float v = secB.y / (secB.y - secA.y);
 						secA = f3_lerp(secB, secA, v);
 					}
-				} else {
+				} else if (secB.y <= 0.0f) {
 					float v = secA.y / (secA.y - secB.y);
 					secB = f3_lerp(secA, secB, v);
-					secBKept = false;
 				}
+				secBQuotient = secB.x / secB.z; // (secB unchanged and projected by the side block: the same operands, the same quotient)
 			}
-			if (CVX_USUAL(visible)) {
+			{
 				CVX_COUNT(11);
 				float bx = rintf(secA.x / secA.z);
-				if (CVX_RARE(!secBKept)) {
-					secBQuotient = secB.x / secB.z; // (a side that was entirely behind the near plane, or a clipped secB: rare)
-				}
 				float by = rintf(secBQuotient);
 				int rbMin = f2i(bx);
 				int rbMax = f2i(by);
 				if (rbMin > rbMax) {
 					int t = rbMin; rbMin = rbMax; rbMax = t;
 				}
-				if (CVX_USUAL(((int)(rbMax >= nextFreePixelMin) & (int)(rbMin <= nextFreePixelMax)) != 0)) {
+				if (CVX_USUAL(((int)visible & (int)(rbMax >= nextFreePixelMin) & (int)(rbMin <= nextFreePixelMax)) != 0)) {
 					CVX_COUNT(12);
 					reduce_pixel_horizon(seen, sshift, omin, omax, rbMin, rbMax, nextFreePixelMin, nextFreePixelMax, frustumBoundsMin, frustumBoundsMax);
 					CVX_END(6);
@@ -1062,12 +1070,12 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		lastColumnDrawn = false; // an empty or culled column breaks the chain
 		lastColumnClipped = false;
 #endif
-		if ((header.z >> 16) != 0u) { // RunCount > 0: not an empty column (:251-256)
+		{
 			bool draw = true;
 			worldBoundsMin = 0.0f;
 			worldBoundsMax = worldMaxY;
-			{ // :261-281, straight-line: the tests as flags (`&` / `|`: no nested divergent regions), the bounds as selects
-				const bool cull = frustumDirMaxWorld != CVX_FLOAT_EPSILON;
+			{ // :251-256 (RunCount > 0: not an empty column) and :261-281, straight-line: the tests as flags (`&` / `|`: no nested divergent regions), the bounds as selects
+				const bool cull = ((int)((header.z >> 16) != 0u) & (int)(frustumDirMaxWorld != CVX_FLOAT_EPSILON)) != 0;
 				const float columnWorldMin = (float)(header.y >> 16);
 				const float columnWorldMax = (float)(header.z & 0xFFFFu);
 				const float distTop = frustumDirMaxWorld > 0.0f ? curDistNext : curDistLast;
@@ -1078,7 +1086,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 				const bool noOverlap = ((int)cull & ((int)(columnWorldMin > newMax) | (int)(columnWorldMax < newMin))) != 0; // this column does not overlap the writable world bounds
 				const bool narrowed = ((int)cull & (int)!leftWorld & (int)!noOverlap) != 0;
 				alive = !leftWorld;
-				draw = (((int)leftWorld | (int)noOverlap)) == 0;
+				draw = ((int)((header.z >> 16) != 0u) & (int)!leftWorld & (int)!noOverlap) != 0;
 				worldBoundsMin = narrowed ? newMin : worldBoundsMin;
 				worldBoundsMax = narrowed ? newMax : worldBoundsMax;
 			}
