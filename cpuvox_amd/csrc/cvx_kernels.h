@@ -683,22 +683,22 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			bool found = false;
 			CVX_BEGIN();
 			CVX_WAITPROBE(10);
-			if (!COUNT) {
-				// runs beyond the record: rare, so the scan sits behind one branch (bottom-up they come first, top-down last)
-				auto scanOverflow = [&]() {
-					while (DIR > 0 ? ovNext < solidCount : ovNext >= 2) {
-						const uint2 run = ld2(arena, columnRunsOff + (uint32_t)(ovNext - 2) * 8u);
-						ovNext += DIR > 0 ? 1 : -1;
-						runSpan(run.x, elementBoundsMin, elementBoundsMax);
-						if (!(elementBoundsMin > worldBoundsMax) && !(elementBoundsMax < worldBoundsMin)) {
-							elementLength = (int)(run.x >> 16);
-							elementColorsIndex = (int)(run.y & 0xFFFFu);
-							found = true;
-							break;
-						}
+			// runs beyond the record: rare, so the scan sits behind one branch (bottom-up they come first, top-down last)
+			auto scanOverflow = [&]() {
+				while (DIR > 0 ? ovNext < solidCount : ovNext >= 2) {
+					const uint2 run = ld2(arena, columnRunsOff + (uint32_t)(ovNext - 2) * 8u);
+					ovNext += DIR > 0 ? 1 : -1;
+					runSpan(run.x, elementBoundsMin, elementBoundsMax);
+					if (!(elementBoundsMin > worldBoundsMax) && !(elementBoundsMax < worldBoundsMin)) {
+						elementLength = (int)(run.x >> 16);
+						elementColorsIndex = (int)(run.y & 0xFFFFu);
+						found = true;
+						break;
 					}
-					ovPending = DIR > 0 ? ovNext < solidCount : ovNext >= 2;
-				};
+				}
+				ovPending = DIR > 0 ? ovNext < solidCount : ovNext >= 2;
+			};
+			if (!COUNT) {
 				if (DIR < 0 && CVX_RARE(ovPending)) {
 					scanOverflow();
 				}
@@ -725,9 +725,6 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 					found = ((int)found | (int)take) != 0;
 					vis0 = vis0 && !take0;
 					vis1 = vis1 && !take1;
-				}
-				if (DIR > 0 && !found && CVX_RARE(ovPending)) {
-					scanOverflow();
 				}
 			}
 			while (COUNT && solidIndex < solidCount) {
@@ -763,10 +760,15 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 				break;
 			}
 			CVX_END(3);
-			if (COUNT ? !found : CVX_RARE(!found)) { // (rendering build: only a lane whose remaining runs beyond the record are all invisible)
+			if (COUNT ? !found : CVX_RARE(!found)) { // (rendering build: only a lane that has nothing visible left in the record)
 				if (COUNT && solidIndex == solidCount) { consumed = (header.z >> 16) + 1u; } // walked on to the end guard
 				if (COUNT) { break; }
-				continue; // (rendering build: nothing is pending any more, so the loop condition ends it -- one way out of the loop instead of two)
+				if (DIR > 0) { // top-down the runs beyond the record come last (here, behind the same rare branch)
+					scanOverflow();
+				}
+				if (!found) {
+					continue; // (nothing is pending any more, so the loop condition ends it -- one way out of the loop instead of two)
+				}
 			}
 
 			// unlerp(0, worldMaxY, x) = (x - 0) / (worldMaxY - 0); worldMaxY is a power of two (enforced at upload), so
@@ -796,8 +798,24 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 				float uA = (float)elementLength;
 				float uB = 0.0f;
 				bool visible = true; // ClipHomogeneousCameraSpaceLine with u, CameraData.cs:141-157
-				bool nearClipped = false;
-				if (CVX_RARE(((int)(camSpaceFrontBottom.y <= 0.0f) | (int)(camSpaceFrontTop.y <= 0.0f)) != 0)) { // (one test on the common path)
+				// uvA = (1, uA) / bottom.z, uvB = (1, uB) / top.z (:490-493) and ProjectClippedToScreen (CameraData.cs:160) of both ends:
+				// three numerators per denominator.  Ordinary case (nothing near-clipped, so uA = the run length in [1, 65535] and
+				// uB = 0, and all of x, z of both ends within [2^-30, 2^30]): one refined reciprocal per end (see quot_safe).  Every lane
+				// computes that; ONE rare branch then redoes the lanes that are not ordinary -- an end behind the near plane (:141-157) or an
+				// operand outside the range -- with the clip and the plain divisions (an if / else costs two branches, a test per case one each).
+				float uvAx, uvAy, uvBx, uvBy;
+				{
+					const Recip rb = recip_safe(camSpaceFrontBottom.z), rt = recip_safe(camSpaceFrontTop.z);
+					uvAx = quot_safe(1.0f, rb);
+					uvAy = quot_safe(uA, rb);
+					frontBottomQuotient = quot_safe(camSpaceFrontBottom.x, rb);
+					uvBx = quot_safe(1.0f, rt);
+					uvBy = __int_as_float(__float_as_int(camSpaceFrontTop.z) & (int)0x80000000); // +0 / z: a zero with the sign of z
+					frontTopQuotient = quot_safe(camSpaceFrontTop.x, rt);
+				}
+				const bool ordinary = ((int)!(camSpaceFrontBottom.y <= 0.0f) & (int)!(camSpaceFrontTop.y <= 0.0f) & (int)div_safe(camSpaceFrontBottom.z) & (int)div_safe(camSpaceFrontTop.z) &
+				                       (int)div_safe(camSpaceFrontBottom.x) & (int)div_safe(camSpaceFrontTop.x)) != 0;
+				if (CVX_RARE(!ordinary)) {
 					if (camSpaceFrontBottom.y <= 0.0f) {
 						if (camSpaceFrontTop.y <= 0.0f) {
 							visible = false;
@@ -805,40 +823,22 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 							float v = camSpaceFrontTop.y / (camSpaceFrontTop.y - camSpaceFrontBottom.y);
 							camSpaceFrontBottom = f3_lerp(camSpaceFrontTop, camSpaceFrontBottom, v);
 							uA = m_lerp(uB, uA, v);
-							nearClipped = true;
 						}
-					} else {
+					} else if (camSpaceFrontTop.y <= 0.0f) {
 						float v = camSpaceFrontBottom.y / (camSpaceFrontBottom.y - camSpaceFrontTop.y);
 						camSpaceFrontTop = f3_lerp(camSpaceFrontBottom, camSpaceFrontTop, v);
 						uB = m_lerp(uA, uB, v);
-						nearClipped = true;
 					}
+					uvAx = 1.0f / camSpaceFrontBottom.z;
+					uvAy = uA / camSpaceFrontBottom.z;
+					uvBx = 1.0f / camSpaceFrontTop.z;
+					uvBy = uB / camSpaceFrontTop.z;
+					frontBottomQuotient = camSpaceFrontBottom.x / camSpaceFrontBottom.z;
+					frontTopQuotient = camSpaceFrontTop.x / camSpaceFrontTop.z;
 				}
 				haveFrontQuotients = visible;
-				{ // (a side entirely behind the near plane runs through the projection with whatever it holds and fails the overlap test below: no branch of its own)
+				{ // (a side entirely behind the near plane runs through the rest with whatever it holds and fails the overlap test below: no branch of its own)
 					CVX_COUNT(9);
-					// uvA = (1, uA) / bottom.z, uvB = (1, uB) / top.z (:490-493) and ProjectClippedToScreen (CameraData.cs:160) of both ends:
-					// three numerators per denominator.  Ordinary case (nothing near-clipped, so uA = the run length in [1, 65535] and
-					// uB = 0, and all of x, z of both ends within [2^-30, 2^30]): one refined reciprocal per end (see quot_safe).
-					float uvAx, uvAy, uvBx, uvBy;
-					// (computed by every lane, and replaced behind ONE rare branch where the operands are not in that range: an if / else costs two)
-					{
-						const Recip rb = recip_safe(camSpaceFrontBottom.z), rt = recip_safe(camSpaceFrontTop.z);
-						uvAx = quot_safe(1.0f, rb);
-						uvAy = quot_safe(uA, rb);
-						frontBottomQuotient = quot_safe(camSpaceFrontBottom.x, rb);
-						uvBx = quot_safe(1.0f, rt);
-						uvBy = __int_as_float(__float_as_int(camSpaceFrontTop.z) & (int)0x80000000); // +0 / z: a zero with the sign of z
-						frontTopQuotient = quot_safe(camSpaceFrontTop.x, rt);
-					}
-					if (CVX_RARE(!(!nearClipped && div_safe(camSpaceFrontBottom.z) && div_safe(camSpaceFrontTop.z) && div_safe(camSpaceFrontBottom.x) && div_safe(camSpaceFrontTop.x)))) {
-						uvAx = 1.0f / camSpaceFrontBottom.z;
-						uvAy = uA / camSpaceFrontBottom.z;
-						uvBx = 1.0f / camSpaceFrontTop.z;
-						uvBy = uB / camSpaceFrontTop.z;
-						frontBottomQuotient = camSpaceFrontBottom.x / camSpaceFrontBottom.z;
-						frontTopQuotient = camSpaceFrontTop.x / camSpaceFrontTop.z;
-					}
 					sharedQuotient = faceTop ? frontTopQuotient : frontBottomQuotient;
 					float boundsX = frontBottomQuotient;
 					float boundsY = frontTopQuotient;
