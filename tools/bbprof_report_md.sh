@@ -46,15 +46,23 @@ for i in range(lo,hi):
         mm=re.match(r"\.loc\s+\d+\s+(\d+)",s)
         if mm: loc=int(mm.group(1)); continue
         if s.startswith('s_waitcnt'): rows[(s.split(None,1)[1],loc)]+=e
+ksrc=open(os.path.join(os.getcwd(),'cpuvox_amd','csrc','cvx_kernels.h')).read().split('\n')
+def ln(pat, after=0):
+    return next(i+1 for i,l in enumerate(ksrc) if i+1>after and pat in l)
+L_ld=ln('__device__ __forceinline__ uint4 ld4('); L_st=ln('void st_pixel('); L_rec=ln('uint32_t record_offset(')
+L_dda=ln('bool dda_step('); L_scan=ln('int scan_up('); L_scan_end=ln('bits of word w that fall')
+L_walk=ln('// ---- element loop, :424-611'); L_portion=ln('const float portionBottom = '); L_side=ln('// side of the run, :484-542')
+L_sidepix=ln('// pixel loop :519-533'); L_sidepix_end=ln('CVX_END(5);'); L_facepix=ln('// :595-603'); L_facepix_end=ln('CVX_END(7);')
+L_step=ln('auto columnStep = '); L_step_end=ln('while (alive) {')
 def what(w,loc):
     if loc is None or loc==0: return "compiler-placed (join)"
-    if loc in (66,67,68) or 1025<=loc<=1075 or 250<=loc<=270: return "record of the column now being processed (its two loads were issued one step earlier as the look-ahead)" if 'vmcnt' in w else ""
-    if 317<=loc<=360: return "LDS mask word of a horizon scan"
-    if 840<=loc<=890 and 'lgkm' in w: return "LDS mask word of the side pixel loop"
-    if 930<=loc<=960 and 'lgkm' in w: return "LDS mask word of the face pixel loop"
-    if loc in (48,50): return "colour loads ahead of the pixel stores"
-    if 640<=loc<=760: return "record words of the current column / run-list entry (columns with > 2 solid runs)"
-    if 760<=loc<=800: return "face colour / record words before the side projection"
+    if L_ld<=loc<=L_ld+2 or L_rec-1<=loc<=L_rec+5 or L_step<=loc<=L_step_end or L_dda<=loc<=L_dda+20: return "record of the column now being processed (its two loads were issued one step earlier as the look-ahead)" if 'vmcnt' in w else ""
+    if L_scan<=loc<=L_scan_end+30: return "LDS mask word of a horizon scan"
+    if L_sidepix<=loc<=L_sidepix_end and 'lgkm' in w: return "LDS mask word of the side pixel loop"
+    if L_facepix<=loc<=L_facepix_end and 'lgkm' in w: return "LDS mask word of the face pixel loop"
+    if L_st-1<=loc<=L_st+3: return "colour loads ahead of the pixel stores"
+    if L_walk<=loc<L_portion: return "record words of the current column / run-list entry (columns with > 2 solid runs)"
+    if L_portion<=loc<=L_side+40: return "face colour / record words before the side projection"
     return ""
 for (w,loc),e in sorted(rows.items(), key=lambda kv:-kv[1]):
     if e/S<0.01: continue
