@@ -316,41 +316,32 @@ __device__ __forceinline__ bool clip_world_bounds(f3 pMin, f3 pMax, float fMin, 
 // (the reference's while loop at :407 / :678 does not run then).
 __device__ __forceinline__ int scan_up(const uint32_t *seen, int sshift, int start, int omax)
 {
-	if (CVX_RARE(start > omax)) {
-		return start;
-	}
-	int w = start >> 5;
+	// (one way through: the word index clamped into the window, the special results as selects)
 	const int wend = omax >> 5;
+	int w = min(start >> 5, wend);
 	uint32_t m = ~seen[w << sshift] & (0xFFFFFFFFu << (start & 31));
 	while (m == 0u && w < wend) {
 		w++;
 		m = ~seen[w << sshift];
 	}
-	if (CVX_RARE(m == 0u)) {
-		return omax + 1;
-	}
-	int pos = (w << 5) + (__ffs((int)m) - 1);
-	return pos > omax ? omax + 1 : pos;
+	const int pos = (w << 5) + (__ffs((int)m) - 1);
+	const int found = (m == 0u || pos > omax) ? omax + 1 : pos;
+	return start > omax ? start : found;
 }
 
 // last unseen pixel <= start, or omin-1; start unchanged when start < omin (:413 / :690).
 __device__ __forceinline__ int scan_down(const uint32_t *seen, int sshift, int start, int omin)
 {
-	if (CVX_RARE(start < omin)) {
-		return start;
-	}
-	int w = start >> 5;
 	const int wbeg = omin >> 5;
+	int w = max(start >> 5, wbeg);
 	uint32_t m = ~seen[w << sshift] & (0xFFFFFFFFu >> (31 - (start & 31)));
 	while (m == 0u && w > wbeg) {
 		w--;
 		m = ~seen[w << sshift];
 	}
-	if (CVX_RARE(m == 0u)) {
-		return omin - 1;
-	}
-	int pos = (w << 5) + (31 - __clz((int)m));
-	return pos < omin ? omin - 1 : pos;
+	const int pos = (w << 5) + (31 - __clz((int)m));
+	const int found = (m == 0u || pos < omin) ? omin - 1 : pos;
+	return start < omin ? start : found;
 }
 
 // bits of word w that fall inside [lo, hi]
@@ -464,10 +455,12 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		if (!dda_step_to_world_intersection(ray, (float)dimX, (float)dimZ)) {
 			return; // WriteSkyboxFull
 		}
-		while (ray.distLast >= lodMax && lod < 5) { // lod < 5: memory-safety guard only, such a ray is beyond far clip anyway
+		// (the threshold of the last level is taken as +infinity -- `lod < 5` of :237 / :101, a memory-safety guard only: such a ray is beyond far clip
+		// anyway -- so the test of every column step below is ONE compare)
+		while (ray.distLast >= lodMax) {
 			dda_next_lod(ray, 1 << lod, dirXNonNegative, dirZNonNegative);
 			lod++;
-			lodMax = F.lod[lod];
+			{ const float next_ = F.lod[min(lod, 5)]; lodMax = lod < 5 ? next_ : __builtin_inff(); }
 		}
 		if (m_min(ray.tMaxX, ray.tMaxZ) >= farClip) { // IsBeyondFarClip, SegmentDDAData.cs:152
 			return; // WriteSkyboxFull
@@ -792,8 +785,13 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			CVX_COUNT(4);
 			// x / z of the front end the face shares with the side (:570-571 project the same point again): kept from the side
 			// block unless the face's own near clip moves the point
-			float frontBottomQuotient, frontTopQuotient, sharedQuotient = 0.0f;
-			bool haveFrontQuotients;
+			float frontBottomQuotient, frontTopQuotient;
+			// The face's two ends (:566-571) ahead of the side: secA = the back end (on the Next intersection), secB = the front end the face shares with the
+			// side, whose x / z (:570-571 project the same point again) is kept from the side block.  Pure arithmetic, and with it ONE rare branch serves the
+			// near-plane clips of both blocks.
+			f3 secA = f3_lerp(camSpaceMinNext, camSpaceMaxNext, faceTop ? portionTop : portionBottom);
+			float secBQuotient;
+			bool faceVisible = faceWanted; // ClipHomogeneousCameraSpaceLine of the face, CameraData.cs:124-138 (a face that is not wanted runs through its block as "not visible")
 			{
 				float uA = (float)elementLength;
 				float uB = 0.0f;
@@ -813,7 +811,8 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 					uvBy = __int_as_float(__float_as_int(camSpaceFrontTop.z) & (int)0x80000000); // +0 / z: a zero with the sign of z
 					frontTopQuotient = quot_safe(camSpaceFrontTop.x, rt);
 				}
-				const bool ordinary = ((int)!(camSpaceFrontBottom.y <= 0.0f) & (int)!(camSpaceFrontTop.y <= 0.0f) & (int)div_safe(camSpaceFrontBottom.z) & (int)div_safe(camSpaceFrontTop.z) &
+				secBQuotient = faceTop ? frontTopQuotient : frontBottomQuotient;
+				const bool ordinary = ((int)!(camSpaceFrontBottom.y <= 0.0f) & (int)!(camSpaceFrontTop.y <= 0.0f) & (int)!(secA.y <= 0.0f) & (int)div_safe(camSpaceFrontBottom.z) & (int)div_safe(camSpaceFrontTop.z) &
 				                       (int)div_safe(camSpaceFrontBottom.x) & (int)div_safe(camSpaceFrontTop.x)) != 0;
 				if (CVX_RARE(!ordinary)) {
 					if (camSpaceFrontBottom.y <= 0.0f) {
@@ -835,17 +834,31 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 					uvBy = uB / camSpaceFrontTop.z;
 					frontBottomQuotient = camSpaceFrontBottom.x / camSpaceFrontBottom.z;
 					frontTopQuotient = camSpaceFrontTop.x / camSpaceFrontTop.z;
+					// the face's clip (:124-138) with the front end as the side's clip left it
+					f3 secB = faceTop ? camSpaceFrontTop : camSpaceFrontBottom;
+					if (secA.y <= 0.0f) {
+						if (secB.y <= 0.0f) {
+							faceVisible = false;
+						} else {
+							float v = secB.y / (secB.y - secA.y);
+							secA = f3_lerp(secB, secA, v);
+						}
+					} else if (secB.y <= 0.0f) {
+						float v = secA.y / (secA.y - secB.y);
+						secB = f3_lerp(secA, secB, v);
+					}
+					secBQuotient = secB.x / secB.z; // (an unclipped secB: the operands of the front quotient above, the same quotient)
 				}
-				haveFrontQuotients = visible;
 				{ // (a side entirely behind the near plane runs through the rest with whatever it holds and fails the overlap test below: no branch of its own)
 					CVX_COUNT(9);
-					sharedQuotient = faceTop ? frontTopQuotient : frontBottomQuotient;
 					float boundsX = frontBottomQuotient;
 					float boundsY = frontTopQuotient;
-					if (boundsX > boundsY) {
-						float t = boundsX; boundsX = boundsY; boundsY = t;
-						t = uvAx; uvAx = uvBx; uvBx = t;
-						t = uvAy; uvAy = uvBy; uvBy = t;
+					{ // :496-499, the swap of the two ends as selects
+						const bool sw = boundsX > boundsY;
+						const float bx_ = sw ? boundsY : boundsX, by_ = sw ? boundsX : boundsY;
+						const float ax_ = sw ? uvBx : uvAx, bxx_ = sw ? uvAx : uvBx;
+						const float ay_ = sw ? uvBy : uvAy, byy_ = sw ? uvAy : uvBy;
+						boundsX = bx_; boundsY = by_; uvAx = ax_; uvBx = bxx_; uvAy = ay_; uvBy = byy_;
 					}
 					int rbMin = f2i(rintf(boundsX));
 					int rbMax = f2i(rintf(boundsY));
@@ -908,27 +921,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			// (a run seen from the side, or whose face lies outside the world bounds (:551,558,564), goes through the face block as "not visible": the
 			// block is straight-line up to the overlap test, and some lane of the wave needs it anyway)
 			if (COUNT && faceWanted) { cnt.C++; }
-			f3 secA = f3_lerp(camSpaceMinNext, camSpaceMaxNext, faceTop ? portionTop : portionBottom);
-			f3 secB = faceTop ? camSpaceFrontTop : camSpaceFrontBottom;
-			float secBQuotient = sharedQuotient;
-
 			CVX_COUNT(6);
-			bool visible = faceWanted; // ClipHomogeneousCameraSpaceLine, CameraData.cs:124-138
-			// (ONE test on the common path: an end behind the near plane, or secB no longer the front end the side block projected)
-			if (CVX_RARE(((int)(secA.y <= 0.0f) | (int)(secB.y <= 0.0f) | (int)!haveFrontQuotients) != 0)) {
-				if (secA.y <= 0.0f) {
-					if (secB.y <= 0.0f) {
-						visible = false;
-					} else {
-						float v = secB.y / (secB.y - secA.y);
-						secA = f3_lerp(secB, secA, v);
-					}
-				} else if (secB.y <= 0.0f) {
-					float v = secA.y / (secA.y - secB.y);
-					secB = f3_lerp(secA, secB, v);
-				}
-				secBQuotient = secB.x / secB.z; // (secB unchanged and projected by the side block: the same operands, the same quotient)
-			}
 			{
 				CVX_COUNT(11);
 				float bx = rintf(secA.x / secA.z);
@@ -938,7 +931,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 				if (rbMin > rbMax) {
 					int t = rbMin; rbMin = rbMax; rbMax = t;
 				}
-				if (CVX_USUAL(((int)visible & (int)(rbMax >= nextFreePixelMin) & (int)(rbMin <= nextFreePixelMax)) != 0)) {
+				if (CVX_USUAL(((int)faceVisible & (int)(rbMax >= nextFreePixelMin) & (int)(rbMin <= nextFreePixelMax)) != 0)) {
 					CVX_COUNT(12);
 					reduce_pixel_horizon(seen, sshift, omin, omax, rbMin, rbMax, nextFreePixelMin, nextFreePixelMax, frustumBoundsMin, frustumBoundsMax);
 					CVX_END(6);
@@ -976,12 +969,12 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 	};
 
 	// column 0: LOD check (:237-243), bounds test and fetch (World.GetVoxelColumn, World.cs:130-142)
-	if (ray.distLast >= lodMax && lod < 5) {
+	if (ray.distLast >= lodMax) {
 		dda_next_lod(ray, voxelScale, dirXNonNegative, dirZNonNegative);
 		lod++;
 		voxelScale *= 2;
 		L = world->level[lod];
-		lodMax = F.lod[lod];
+		{ const float next_ = F.lod[min(lod, 5)]; lodMax = lod < 5 ? next_ : __builtin_inff(); }
 	}
 	if ((ray.px & maskX) != ray.px || (ray.pz & maskZ) != ray.pz) {
 		return; // out of world bounds -> WriteSkybox
@@ -996,7 +989,8 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 	// merged at every join on the way out.
 	bool alive = true;
 	// one column step: `header` / `queue` = the column to process (already fetched), `nextHeader` / `nextQueue` receive the look-ahead
-	auto columnStep = [&](const uint4 &header, const uint4 &queue, uint4 &nextHeader, uint4 &nextQueue) {
+	auto columnStep = [&](const uint4 &header, const uint4 &queue, uint4 &nextHeader, uint4 &nextQueue, auto guardTag) {
+		constexpr bool GUARD = decltype(guardTag)::value;
 		CVX_BEGIN();
 		CVX_WAITPROBE(9);
 		CVX_COUNT(1);
@@ -1044,12 +1038,12 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		const bool lastColumn = dda_step(ray, farClip); // true: far clip reached after this column
 		// (the LOD check and the fetch are done for every lane, also one that stops after this column: its state is
 		// dead, and an unconditional, in-bounds load is cheaper than branching around it)
-		if (CVX_RARE(ray.distLast >= lodMax && lod < 5)) {
+		if (CVX_RARE(ray.distLast >= lodMax)) {
 			dda_next_lod(ray, voxelScale, dirXNonNegative, dirZNonNegative);
 			lod++;
 			voxelScale *= 2;
 			L = world->level[lod];
-			lodMax = F.lod[lod];
+			{ const float next_ = F.lod[min(lod, 5)]; lodMax = lod < 5 ? next_ : __builtin_inff(); }
 		}
 		const bool nextOutside = (ray.px & maskX) != ray.px || (ray.pz & maskZ) != ray.pz;
 		const uint32_t rec = L.recordsOff + record_offset((ray.px & maskX) >> L.shift, (ray.pz & maskZ) >> L.shift, L.tilesZShift); // clamped into the table
@@ -1103,16 +1097,16 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		}
 
 		// ---- next column (far clip reached / left the world: WriteSkybox; the step guard never binds on valid input)
-		guardSteps--;
-		alive = alive && !(lastColumn || nextOutside) && guardSteps > 0;
+		if (GUARD) { guardSteps--; } // (counted in one of the two copies of the step: the cap is generous by more than a factor of two)
+		alive = alive && !(lastColumn || nextOutside) && (!GUARD || guardSteps > 0);
 		CVX_END(1);
 	};
 	// The loop alternates between two register sets for the record pair, so the look-ahead record never has to be copied into "the
 	// current one" at the end of a step (8 v_mov per step); the code of a step exists twice for it.
 	while (alive) {
-		columnStep(header, queue, headerB, queueB);
+		columnStep(header, queue, headerB, queueB, std::true_type{});
 		if (alive) {
-			columnStep(headerB, queueB, header, queue);
+			columnStep(headerB, queueB, header, queue, std::false_type{});
 		}
 	}
 }
