@@ -513,10 +513,6 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 	uint4 header, queue;              // record of the current column: header + its first two solid runs in walk order
 	uint4 headerB, queueB;            // ... and of the next one (the column loop alternates between the two pairs: no copies at the end of a step)
 	float curDistLast, curDistNext;   // ray.IntersectionDistances of the current column
-	int curScale;                     // voxelScale of the current column (counting build)
-	int curShift;                     // its log2 = the LOD of the current column
-	uint32_t curElementsOff;          // element pool of the current column's LOD (colours): byte offset in the arena
-	uint32_t curRunsOff;              // run list (solid runs 2..) of the current column's LOD
 	unsigned int consumed = 0u;       // counting variant: elements the reference's walk has dereferenced in this column
 	float worldBoundsMin, worldBoundsMax;
 #ifdef CVX_PROFILE_COUNTS
@@ -534,7 +530,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		const int solidCount = (int)(header.y & 0xFFFFu);
 		CVX_BEGIN();
 		if (COUNT) { consumed = 0u; }
-		const uint32_t columnRunsOff = curRunsOff + header.w * 8u; // solid run j >= 2 (top-down numbering) lives at entry j - 2
+		const uint32_t columnRunsOff = L.runsOff + header.w * 8u; // solid run j >= 2 (top-down numbering) lives at entry j - 2
 		// :289-293
 		const f3 camSpaceMinLast = f3_madd(planeStartBottom, planeDir, curDistLast);
 		const f3 camSpaceMinNext = f3_madd(planeStartBottom, planeDir, curDistNext);
@@ -638,7 +634,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		// bounds the reference accumulates are exactly these integers), so only solid runs are iterated here.
 		float elementBoundsMin, elementBoundsMax;
 		int solidIndex = 0;
-		const uint32_t worldColumnColorsOff = curElementsOff + header.x * 4u; // ColorPointer, World.cs:185
+		const uint32_t worldColumnColorsOff = L.elementsOff + header.x * 4u; // ColorPointer, World.cs:185
 
 		// Rendering build: which solid runs the walk below would project is decided without walking.  A run is projected iff it is
 		// neither entirely above worldBoundsMax (:461-467) nor entirely below worldBoundsMin (:468-475) -- the reference's early
@@ -650,9 +646,9 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		int ovNext = 0; // next run beyond the record to look at: 2, 3, ... (top-down walk) or solidCount - 1, ... 2 (bottom-up walk)
 		// world-space span of a run word {start | length << 16}: [top - length, top] in LOD-0 voxels (integers, see the walk below)
 		auto runSpan = [&](uint32_t w0, float &bottom, float &top) {
-			const int t = worldMaxYInt - (int)((w0 & 0xFFFFu) << curShift);
+			const int t = worldMaxYInt - (int)((w0 & 0xFFFFu) << lod);
 			top = (float)t;
-			bottom = (float)(t - (int)((w0 >> 16) << curShift));
+			bottom = (float)(t - (int)((w0 >> 16) << lod));
 		};
 		if (!COUNT) {
 			float b0, t0, b1, t1;
@@ -740,9 +736,9 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 				if (COUNT) { consumed = DIR > 0 ? (w1 >> 16) : (header.z >> 16) + 1u - (w1 >> 16); } // position among all elements in walk order
 				// The run's world-space span.  Top-down the reference accumulates it from worldMaxY (:429-431,449-451), bottom-up from 0
 				// (:433-435,453-455): integer sums either way, and the runs of a column add up to its height, so both are these.
-				const int top = worldMaxYInt - (int)(w0 & 0xFFFFu) * curScale;
+				const int top = worldMaxYInt - (int)(w0 & 0xFFFFu) * voxelScale;
 				elementBoundsMax = (float)top;
-				elementBoundsMin = (float)(top - elementLength * curScale);
+				elementBoundsMin = (float)(top - elementLength * voxelScale);
 				if (elementBoundsMin > worldBoundsMax) {
 					if (DIR < 0) { solidIndex = solidCount + 1; break; } else { continue; }
 				}
@@ -1030,23 +1026,31 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		// next iteration :237-243) and start fetching its record; nothing below touches `ray` again.
 		curDistLast = ray.distLast;
 		curDistNext = ray.distNext;
-		curScale = voxelScale;
-		curShift = lod;
-		curElementsOff = L.elementsOff;
-		curRunsOff = L.runsOff;
-		const int curLod = lod;
 		const bool lastColumn = dda_step(ray, farClip); // true: far clip reached after this column
 		// (the LOD check and the fetch are done for every lane, also one that stops after this column: its state is
 		// dead, and an unconditional, in-bounds load is cheaper than branching around it)
-		if (CVX_RARE(ray.distLast >= lodMax)) {
-			dda_next_lod(ray, voxelScale, dirXNonNegative, dirZNonNegative);
-			lod++;
-			voxelScale *= 2;
-			L = world->level[lod];
-			{ const float next_ = F.lod[min(lod, 5)]; lodMax = lod < 5 ? next_ : __builtin_inff(); }
+		// `lod`, `voxelScale`, `L` describe the level of the CURRENT column all through this step -- drawColumn below reads them, there are no
+		// per-step copies of them.  A LOD switch the look-ahead finds for the next column (:237-243) is applied to the DDA and to the record address at
+		// once, but to those three only at the top of the next step; until then it is marked by lodMax = -infinity, which sends every lane through
+		// the rare branch below once more.
+		uint32_t rec = L.recordsOff + record_offset((ray.px & maskX) >> L.shift, (ray.pz & maskZ) >> L.shift, L.tilesZShift); // clamped into the table
+		if (CVX_RARE(!(ray.distLast < lodMax))) {
+			if (lodMax == -__builtin_inff()) { // the switch found one step ago: this step's column is the first one of the new level
+				lod++;
+				voxelScale *= 2;
+				L = world->level[lod];
+				{ const float next_ = F.lod[min(lod, 5)]; lodMax = lod < 5 ? next_ : __builtin_inff(); }
+			}
+			if (ray.distLast >= lodMax) { // (lod < 5 here: the last level's threshold is +infinity)
+				dda_next_lod(ray, voxelScale, dirXNonNegative, dirZNonNegative);
+				const DevWorldLevel &N = world->level[min(lod + 1, 5)];
+				rec = N.recordsOff + record_offset((ray.px & maskX) >> N.shift, (ray.pz & maskZ) >> N.shift, N.tilesZShift);
+				lodMax = -__builtin_inff();
+			} else {
+				rec = L.recordsOff + record_offset((ray.px & maskX) >> L.shift, (ray.pz & maskZ) >> L.shift, L.tilesZShift);
+			}
 		}
 		const bool nextOutside = (ray.px & maskX) != ray.px || (ray.pz & maskZ) != ray.pz;
-		const uint32_t rec = L.recordsOff + record_offset((ray.px & maskX) >> L.shift, (ray.pz & maskZ) >> L.shift, L.tilesZShift); // clamped into the table
 		nextHeader = ld4(arena, rec);
 		nextQueue = ld4(arena, rec + 16u);
 
@@ -1054,10 +1058,10 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		if (COUNT) {
 			cnt.S++;
 #pragma unroll
-			for (int k = 0; k < 6; k++) { cnt.lod[k] += (curLod == k) ? 1u : 0u; }
+			for (int k = 0; k < 6; k++) { cnt.lod[k] += (lod == k) ? 1u : 0u; }
 		}
 #ifdef CVX_PROFILE_COUNTS
-		const bool sameLod = curLod == lod; // (the look-ahead has already applied a LOD switch for the next column)
+		const bool sameLod = lodMax != -__builtin_inff(); // (no LOD switch pending for the next column)
 		const bool prevDrawn = lastColumnDrawn, prevClipped = lastColumnClipped;
 		prevDrawnShared = prevDrawn;
 		prevClippedShared = prevClipped;
