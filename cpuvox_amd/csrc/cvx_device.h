@@ -18,7 +18,6 @@
 
 #define CVX_WAVE 64
 #define CVX_SKYBOX_ARGB 0x191919FFu /* ColorARGB32(25,25,25): bytes FF 19 19 19 (DrawSegmentRayJob.cs:702) */
-#define CVX_TILE_SHIFT 3            /* column records are stored in tiles of 8 x 8 columns */
 
 struct DevWorldLevel {
 	// One 32-byte record per column.  The reference walks every RLE element of a column (air runs only move the bounds,
@@ -33,13 +32,16 @@ struct DevWorldLevel {
 	//         w0 = start | length << 16      start = voxels (of this LOD) between the top of the column and the run
 	//         w1 = colorsIndex | elementIndex << 16   elementIndex = 1-based position of the run among ALL elements, top-down
 	//              (only the counting variant reads it: it restores the reference's element count E)
-	// Record of column (x, z) (LOD-0 coordinates): cx = x >> shift, cz = z >> shift;
-	//   index = ((cx >> 3 << tilesZShift) + (cz >> 3)) * 64 + (cx & 7) * 8 + (cz & 7)
+	// Record of column (x, z) (LOD-0 coordinates): cx = x >> shift, cz = z >> shift; index = (cx << rowShift) + cz -- row-major, so that
+	// a DDA step moves the record address by a per-ray constant (+- 32 << rowShift bytes along x, +- 32 along z) and the column loop adds
+	// instead of recomputing it (round 2's 8 x 8 tiles cost 14 vector instructions per step and bought nothing: a 128-byte line holds four
+	// z-neighbours either way).  A table is preceded and followed by at least one row + 64 bytes of arena that belong to nothing: a ray
+	// that leaves the world fetches (and never looks at) the record one step outside.
 	uint32_t recordsOff;  // byte offsets from DevWorld::arena
 	uint32_t runsOff;     // uint2 per solid run k >= 2
 	uint32_t elementsOff; // the reference's element pool (RLEElement / ColorARGB32); the kernel reads colours only
 	int32_t shift;        // lod
-	int32_t tilesZShift;  // log2 of the number of 8-column tiles along z
+	int32_t rowShift;     // log2 of the records per row (columns of this level along z)
 	int32_t pad_;
 };
 

@@ -308,14 +308,16 @@ int SyncWorld(cvx_context *ctx)
 				return Fail(ctx, CVX_ERR_NOT_READY, "world LOD %d has not been uploaded (UnityManager.LOD_LEVELS = 6)", i);
 			}
 		}
-		// One arena for all levels: [records | run list | element pool] per level, 256-byte aligned parts, 32-bit offsets.
+		// One arena for all levels: [guard | records | guard | run list | element pool] per level, 256-byte aligned parts, 32-bit offsets.
+		// guard = one row of records + 64 bytes that belong to nothing (cvx_device.h: the fetch of a ray that has just left the world).
 		DevWorld next = ctx->hostWorld;
 		size_t cursor = 0;
 		auto place = [&](size_t bytes) { const size_t at = cursor; cursor = (cursor + bytes + 255) & ~(size_t)255; return at; };
 		size_t recordsAt[CVX_LOD_LEVELS], runsAt[CVX_LOD_LEVELS], elementsAt[CVX_LOD_LEVELS];
 		for (int i = 0; i < CVX_LOD_LEVELS; i++) {
 			const cvx_context::HostLevel &H = ctx->hostLevel[i];
-			recordsAt[i] = place(H.recordsBytes);
+			const size_t guard = (((size_t)32 << H.rowShift) + 64 + 255) & ~(size_t)255;
+			recordsAt[i] = place(guard + H.recordsBytes + guard) + guard;
 			runsAt[i] = place(H.runsBytes);
 			elementsAt[i] = place(H.elementsBytes);
 		}
@@ -354,7 +356,7 @@ int SyncWorld(cvx_context *ctx)
 			L.runsOff = (uint32_t)runsAt[i];
 			L.elementsOff = (uint32_t)(elementsAt[i] + 16); // past the leading guard entries (kPoolPad * 4 bytes)
 			L.shift = i;
-			L.tilesZShift = H.tilesZShift;
+			L.rowShift = H.rowShift;
 			L.pad_ = 0;
 		}
 		if (ctx->arena) { (void)hipFree(ctx->arena); }

@@ -60,11 +60,10 @@ __device__ __forceinline__ void st_pixel(gptr_tile tile, uint32_t laneByteOff, i
 #define ld_color ld1
 #endif
 
-// Byte offset (inside the level's table) of the 32-byte record of LOD column (cx, cz): 8 x 8 tiles, cvx_device.h
-__device__ __forceinline__ uint32_t record_offset(int cx, int cz, int tilesZShift)
+// Byte offset (inside the level's table) of the 32-byte record of LOD column (cx, cz): row-major, cvx_device.h
+__device__ __forceinline__ uint32_t record_offset(int cx, int cz, int rowShift)
 {
-	const uint32_t tile = ((uint32_t)(cx >> CVX_TILE_SHIFT) << tilesZShift) + (uint32_t)(cz >> CVX_TILE_SHIFT);
-	return (((tile << 6) + ((uint32_t)(cx & 7) << 3) + (uint32_t)(cz & 7))) << 5;
+	return (((uint32_t)cx << rowShift) + (uint32_t)cz) << 5;
 }
 
 // ---- Unity.Mathematics scalar semantics (math.cs 1.2.6) --------------------
@@ -251,6 +250,27 @@ __device__ __forceinline__ bool dda_step_to_world_intersection(DDA &d, float dim
 	return true;
 }
 
+// The column loop's form of a ray's position: the column as ONE integer x * 65536 + z (LOD-0 coordinates, multiples of the voxel size of the
+// current level; world dimensions <= 32768, checked at upload) and the byte offset of its record in the level's row-major table, both moved by
+// per-ray constants when the DDA steps (cvx_device.h) -- two instructions each per step instead of a position pair and an address computation.
+// "Outside the world" (:613 / World.cs:130-142, (p & dimensionMask) != p for x or z) is one mask test: a z below 0 borrows from x and leaves
+// 65536 - voxel size in the low half, a z of dimZ sets the bit above maskZ, an x below 0 makes the sum negative, an x of dimX sets the bit
+// above maskX << 16.
+struct ColumnCursor {
+	int pos, posStepX, posStepZ;      // x * 65536 + z and what a step along x / z adds to it
+	uint32_t rec;                     // arena byte offset of the column's record
+	int recStepX, recStepZ;           // +- (32 << rowShift), +- 32
+};
+__device__ __forceinline__ void cursor_set(ColumnCursor &c, const DDA &d, const DevWorldLevel &level, int maskX, int maskZ)
+{
+	c.pos = d.px * 65536 + d.pz;
+	c.posStepX = d.sx * 65536;
+	c.posStepZ = d.sz;
+	c.rec = level.recordsOff + record_offset((d.px & maskX) >> level.shift, (d.pz & maskZ) >> level.shift, level.rowShift); // clamped into the table
+	c.recStepX = (d.sx >> level.shift) * (32 << level.rowShift); // (sx = +- voxel size, or 0 for a ray that never steps along x)
+	c.recStepZ = (d.sz >> level.shift) * 32;
+}
+
 __device__ __forceinline__ bool dda_step(DDA &d, float farClip) // :135-150
 {
 	// branch-free form of "if (tMax.x < tMax.y) step x else step z" (same values, no exec-mask juggling)
@@ -263,6 +283,21 @@ __device__ __forceinline__ bool dda_step(DDA &d, float farClip) // :135-150
 	d.pz += stepX ? 0 : d.sz;
 	d.distLast = crossed;
 	d.distNext = hw_min(d.tMaxX, d.tMaxZ); // tMax values are sums of positive terms: no negative zero, m_min == v_min_f32
+	return crossed >= farClip;
+}
+
+// the same step for the column loop: the position moves in its cursor form (d.px / d.pz / d.sx / d.sz are not touched)
+__device__ __forceinline__ bool dda_step_cursor(DDA &d, ColumnCursor &c, float farClip)
+{
+	const bool stepX = d.tMaxX < d.tMaxZ;
+	const float crossed = stepX ? d.tMaxX : d.tMaxZ;
+	const float nextX = d.tMaxX + d.tDeltaX, nextZ = d.tMaxZ + d.tDeltaZ;
+	d.tMaxX = stepX ? nextX : d.tMaxX;
+	d.tMaxZ = stepX ? d.tMaxZ : nextZ;
+	c.pos += stepX ? c.posStepX : c.posStepZ;
+	c.rec += (uint32_t)(stepX ? c.recStepX : c.recStepZ);
+	d.distLast = crossed;
+	d.distNext = hw_min(d.tMaxX, d.tMaxZ);
 	return crossed >= farClip;
 }
 
@@ -975,11 +1010,11 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 	if ((ray.px & maskX) != ray.px || (ray.pz & maskZ) != ray.pz) {
 		return; // out of world bounds -> WriteSkybox
 	}
-	{
-		const uint32_t rec = L.recordsOff + record_offset(ray.px >> L.shift, ray.pz >> L.shift, L.tilesZShift);
-		header = ld4(arena, rec);
-		queue = ld4(arena, rec + 16u);
-	}
+	ColumnCursor cur;
+	cursor_set(cur, ray, L, maskX, maskZ);
+	const int outsideBits = ~((maskX << 16) | maskZ); // bits of a cursor position that are set only outside the world
+	header = ld4(arena, cur.rec);
+	queue = ld4(arena, cur.rec + 16u);
 
 	// ONE way out of the column loop (`alive`): every early `return` out of a divergent loop costs the structuriser a flag that is
 	// merged at every join on the way out.
@@ -1026,14 +1061,13 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		// next iteration :237-243) and start fetching its record; nothing below touches `ray` again.
 		curDistLast = ray.distLast;
 		curDistNext = ray.distNext;
-		const bool lastColumn = dda_step(ray, farClip); // true: far clip reached after this column
+		const bool lastColumn = dda_step_cursor(ray, cur, farClip); // true: far clip reached after this column
 		// (the LOD check and the fetch are done for every lane, also one that stops after this column: its state is
-		// dead, and an unconditional, in-bounds load is cheaper than branching around it)
+		// dead, and an unconditional load from inside the arena is cheaper than branching around it)
 		// `lod`, `voxelScale`, `L` describe the level of the CURRENT column all through this step -- drawColumn below reads them, there are no
-		// per-step copies of them.  A LOD switch the look-ahead finds for the next column (:237-243) is applied to the DDA and to the record address at
+		// per-step copies of them.  A LOD switch the look-ahead finds for the next column (:237-243) is applied to the DDA and to the cursor at
 		// once, but to those three only at the top of the next step; until then it is marked by lodMax = -infinity, which sends every lane through
 		// the rare branch below once more.
-		uint32_t rec = L.recordsOff + record_offset((ray.px & maskX) >> L.shift, (ray.pz & maskZ) >> L.shift, L.tilesZShift); // clamped into the table
 		if (CVX_RARE(!(ray.distLast < lodMax))) {
 			if (lodMax == -__builtin_inff()) { // the switch found one step ago: this step's column is the first one of the new level
 				lod++;
@@ -1042,15 +1076,18 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 				{ const float next_ = F.lod[min(lod, 5)]; lodMax = lod < 5 ? next_ : __builtin_inff(); }
 			}
 			if (ray.distLast >= lodMax) { // (lod < 5 here: the last level's threshold is +infinity)
+				// back to the DDA's own form of the position (exact for a ray inside the world; one that has just left it is clamped into the table below)
+				ray.px = cur.pos >> 16;
+				ray.pz = cur.pos & 0xFFFF;
+				ray.sx = cur.posStepX >> 16;
+				ray.sz = cur.posStepZ;
 				dda_next_lod(ray, voxelScale, dirXNonNegative, dirZNonNegative);
-				const DevWorldLevel &N = world->level[min(lod + 1, 5)];
-				rec = N.recordsOff + record_offset((ray.px & maskX) >> N.shift, (ray.pz & maskZ) >> N.shift, N.tilesZShift);
+				cursor_set(cur, ray, world->level[min(lod + 1, 5)], maskX, maskZ);
 				lodMax = -__builtin_inff();
-			} else {
-				rec = L.recordsOff + record_offset((ray.px & maskX) >> L.shift, (ray.pz & maskZ) >> L.shift, L.tilesZShift);
 			}
 		}
-		const bool nextOutside = (ray.px & maskX) != ray.px || (ray.pz & maskZ) != ray.pz;
+		const bool nextOutside = (cur.pos & outsideBits) != 0;
+		const uint32_t rec = cur.rec;
 		nextHeader = ld4(arena, rec);
 		nextQueue = ld4(arena, rec + 16u);
 

@@ -167,7 +167,7 @@ __device__ __forceinline__ void trace_wave_sm(const DevFrame &F, const DevSegmen
 			if ((ray.px & maskX) != ray.px || (ray.pz & maskZ) != ray.pz) {
 				alive = false; // out of world bounds -> WriteSkybox
 			} else {
-				const uint32_t rec = L.recordsOff + record_offset(ray.px >> L.shift, ray.pz >> L.shift, L.tilesZShift);
+				const uint32_t rec = L.recordsOff + record_offset(ray.px >> L.shift, ray.pz >> L.shift, L.rowShift);
 				nextHeader = ld4(arena, rec);
 				nextQueue = ld4(arena, rec + 16u);
 			}
@@ -231,7 +231,7 @@ __device__ __forceinline__ void trace_wave_sm(const DevFrame &F, const DevSegmen
 						lodMax = F.lod[lod];
 					}
 					const bool nextOutside = (ray.px & maskX) != ray.px || (ray.pz & maskZ) != ray.pz;
-					const uint32_t rec = L.recordsOff + record_offset((ray.px & maskX) >> L.shift, (ray.pz & maskZ) >> L.shift, L.tilesZShift); // clamped into the table
+					const uint32_t rec = L.recordsOff + record_offset((ray.px & maskX) >> L.shift, (ray.pz & maskZ) >> L.shift, L.rowShift); // clamped into the table
 					nextHeader = ld4(arena, rec);
 					nextQueue = ld4(arena, rec + 16u);
 					pendingEnd = lastColumn || nextOutside;

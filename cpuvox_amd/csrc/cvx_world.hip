@@ -62,6 +62,9 @@ int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byt
 	if (!IsPow2(dimX) || !IsPow2(dimY) || !IsPow2(dimZ) || dimY > 65536) {
 		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "world dimensions must be powers of two (WordBuilder.cs:30), Y <= 65536");
 	}
+	if (dimX > 32768 || dimZ > 32768) { // (the column loop keeps a ray's column as x * 65536 + z in one register; 8192 x 8192 columns already fill the 4 GiB the offsets address)
+		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "world dimensions X, Z must be <= 32768");
+	}
 	if (lod > 0 && !ctx->levelSet[0]) {
 		return Fail(ctx, CVX_ERR_NOT_READY, "upload LOD 0 first: the other levels are checked against its dimensions (World.cs:47)");
 	}
@@ -78,12 +81,11 @@ int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byt
 	const uint32_t *elements = reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(storage) + (size_t)columnCount * 12);
 
 	// Validate every column (so that nothing the kernel dereferences can leave the pool) and build the table of 32-byte
-	// solid-run records (8 x 8 tiles) plus the overflow list (cvx_device.h).  The data goes to the device with the next draw.
+	// solid-run records (row-major) plus the overflow list (cvx_device.h).  The data goes to the device with the next draw.
 	const int maxY = dimY >> lod;
-	const int64_t tilesX = (usedX + 7) >> 3, tilesZ = (usedZ + 7) >> 3;
-	int tilesZShift = 0;
-	while (((int64_t)1 << tilesZShift) < tilesZ) { tilesZShift++; }
-	const size_t recordCount = (size_t)tilesX * ((size_t)1 << tilesZShift) * 64u;
+	int rowShift = 0;
+	while (((int64_t)1 << rowShift) < usedZ) { rowShift++; }
+	const size_t recordCount = (size_t)usedX << rowShift;
 	size_t overflowEntries = 2; // never empty; the kernel may read two entries at any overflowBase
 	for (int64_t i = 0; i < usedColumns; i++) {
 		const RefHeader &h = src[i];
@@ -112,7 +114,7 @@ int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byt
 			}
 			const int64_t off = h.storageOffset;
 			const int n = h.runCount;
-			uint4 *rec = H.records.data() + 2 * ((size_t)(((cx >> 3) << tilesZShift) + (cz >> 3)) * 64u + (size_t)((cx & 7) * 8 + (cz & 7)));
+			uint4 *rec = H.records.data() + 2 * (((size_t)cx << rowShift) + (size_t)cz);
 			uint32_t start = 0, solid = 0;
 			const size_t listBase = overflowCursor;
 			uint2 first[2] = { uint2{ 0u, 0u }, uint2{ 0u, 0u } };
@@ -142,7 +144,7 @@ int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byt
 	H.recordsBytes = H.records.size() * sizeof(uint4);
 	H.runsBytes = H.runs.size() * sizeof(uint2);
 	H.elementsBytes = H.elements.size() * sizeof(uint32_t);
-	H.tilesZShift = tilesZShift;
+	H.rowShift = rowShift;
 	H.pending = true;
 	if (lod == 0) {
 		if (ctx->hostWorld.dimX != dimX || ctx->hostWorld.dimY != dimY || ctx->hostWorld.dimZ != dimZ) {
