@@ -37,14 +37,15 @@ half=len(heads)//2; split=heads[half][0]-3
 sA=sum(e for i,e in heads if i<split); sB=sum(e for i,e in heads if i>=split)
 lo,hi,S=(0,split,sA) if sA>=sB else (split,len(m),sB)
 src=open(os.path.join(os.path.dirname(os.path.abspath(d)),'..','cpuvox_amd','csrc','cvx_kernels.h')).read().split('\n') if False else None
+kfile=next((mm.group(1) for l in lines for mm in [re.match(r'\s*\.file\s+(\d+)\s+.*cvx_kernels\.h"', l)] if mm), None)
 rows=collections.Counter()
 for i in range(lo,hi):
     b=m[i]; a=b['line']; z=m[i+1]['line'] if i+1<len(m) else len(lines)
     e=ex.get(b['block'],0); loc=None
     for l in lines[a:z]:
         s=l.strip()
-        mm=re.match(r"\.loc\s+\d+\s+(\d+)",s)
-        if mm: loc=int(mm.group(1)); continue
+        mm=re.match(r"\.loc\s+(\d+)\s+(\d+)",s)
+        if mm: loc=int(mm.group(2)) if (kfile is None or mm.group(1)==kfile) else loc; continue
         if s.startswith('s_waitcnt'): rows[(s.split(None,1)[1],loc)]+=e
 ksrc=open(os.path.join(os.getcwd(),'cpuvox_amd','csrc','cvx_kernels.h')).read().split('\n')
 def ln(pat, after=0):

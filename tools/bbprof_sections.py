@@ -25,6 +25,8 @@ def line_of(pattern, after=0):
     return next(i + 1 for i, l in enumerate(src) if i + 1 > after and re.search(pattern, l))
 
 
+# `.loc <file> <line>`: only lines of cvx_kernels.h itself count (inlined library code, e.g. __ffs, carries line numbers of other files)
+kfile = next((m.group(1) for l in lines for m in [re.match(r'\s*\.file\s+(\d+)\s+.*cvx_kernels\.h"', l)] if m), None)
 body = line_of(r"void trace_ray\(")
 marks = [
     ("prologue (DDA setup, first column)", body),
@@ -83,9 +85,9 @@ for i in range(lo, hi):
     ins = []
     for l in lines[a:z]:
         s = l.strip()
-        m = re.match(r"\.loc\s+\d+\s+(\d+)", s)
+        m = re.match(r"\.loc\s+(\d+)\s+(\d+)", s)
         if m:
-            loc = int(m.group(1))
+            loc = int(m.group(2)) if kfile is None or m.group(1) == kfile else None
             continue
         if not s or s[0] in ".;" or s.endswith(":"):
             continue
