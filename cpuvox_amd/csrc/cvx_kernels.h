@@ -355,9 +355,11 @@ __device__ __forceinline__ int scan_up(const uint32_t *seen, int sshift, int sta
 	const int wend = omax >> 5;
 	int w = min(start >> 5, wend);
 	uint32_t m = ~seen[w << sshift] & (0xFFFFFFFFu << (start & 31));
-	while (m == 0u && w < wend) {
-		w++;
-		m = ~seen[w << sshift];
+	if (CVX_RARE(((int)(m == 0u) & (int)(w < wend)) != 0)) { // (walking on to further words is the exception: laid out off the common path)
+		do {
+			w++;
+			m = ~seen[w << sshift];
+		} while (m == 0u && w < wend);
 	}
 	const int pos = (w << 5) + (__ffs((int)m) - 1);
 	const int found = (m == 0u || pos > omax) ? omax + 1 : pos;
@@ -370,9 +372,11 @@ __device__ __forceinline__ int scan_down(const uint32_t *seen, int sshift, int s
 	const int wbeg = omin >> 5;
 	int w = max(start >> 5, wbeg);
 	uint32_t m = ~seen[w << sshift] & (0xFFFFFFFFu >> (31 - (start & 31)));
-	while (m == 0u && w > wbeg) {
-		w--;
-		m = ~seen[w << sshift];
+	if (CVX_RARE(((int)(m == 0u) & (int)(w > wbeg)) != 0)) {
+		do {
+			w--;
+			m = ~seen[w << sshift];
+		} while (m == 0u && w > wbeg);
 	}
 	const int pos = (w << 5) + (31 - __clz((int)m));
 	const int found = (m == 0u || pos < omin) ? omin - 1 : pos;
