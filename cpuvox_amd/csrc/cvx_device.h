@@ -79,8 +79,8 @@ struct DevTile { // one workgroup (= one wave) of the render kernel
 	int32_t frame;
 	int32_t seg;
 	int32_t tileInSeg;
-	int32_t lanes; // 0: the wave renders all 64 rays of the tile; else firstLane | laneCount << 8: a sub-tile (small batches are
-	               // split so that a frame alone still spreads over the chip, cvx_gpu.hip DrawBatch)
+	int32_t lanes; // 0: the wave renders all 64 rays of the tile; else firstLane | laneCount << 8 | dupShift << 16: a sub-tile (small batches
+	               // are split so that a frame alone still spreads over the chip, cvx_gpu.hip DrawBatch); 2^dupShift lanes work on every ray of it
 	uint32_t *out; // where pixel row 0, lane 0 of this tile lives (pixel y of lane l at out[y*64 + l]); rows outside
 	               // [origMin, origMax] are never touched, so `out` may point in front of the caller's slot
 };

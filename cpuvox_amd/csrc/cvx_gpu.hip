@@ -771,7 +771,12 @@ int DrawBatch(cvx_context *ctx, int frameCount, const cvx_segment_data *segments
 				continue;
 			}
 			for (int k = 0; k < tileSplit; k++) {
-				t.lanes = (k * lanesPerWave) | (lanesPerWave << 8);
+				// A wave with 8 or fewer active lanes issues vector instructions ~3.6 x slower than one with 16 (tools/valu_rate.hip, gfx950: 11.8 against
+				// 3.2 cycles per instruction and SIMD, whatever the number of resident waves), so the rays of a narrow sub-tile are worked on by 16 / laneCount
+				// lanes each: same addresses, same values, same stores from every lane of a group (not with the counters on: they are summed over lanes).
+				int dupShift = 0;
+				while (!ctx->countersEnabled && (lanesPerWave << dupShift) < CVX_WAVE) { dupShift++; }
+				t.lanes = (k * lanesPerWave) | (lanesPerWave << 8) | (dupShift << 16);
 				sorted.push_back(t);
 #ifdef CVX_TILE_TIMES
 				g_waveSource.push_back(order[i]);

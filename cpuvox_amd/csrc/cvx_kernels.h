@@ -1183,20 +1183,23 @@ __global__ __launch_bounds__(CVX_WAVE, CVX_WAVES_PER_SIMD) void render_kernel(co
 	// RaySetupJob (:19-39): tile -> (segment, planeRayIndex)
 	const int firstLane = tile.lanes & 0xFF, laneCount = tile.lanes ? (tile.lanes >> 8) & 0xFF : CVX_WAVE;
 	const int sshift = 31 - __clz(laneCount); // laneCount is a power of two
-	const int planeRayIndex = tile.tileInSeg * CVX_WAVE + firstLane + lane;
-	const bool active = lane < laneCount && planeRayIndex < S.rayCount;
-	if (lane < laneCount) {
+	// 2^dupShift physical lanes per ray of a narrow sub-tile (cvx_gpu.hip DrawBatch: a wave with <= 8 active lanes issues ~3.6 x slower); the lanes of a
+	// group hold the same values all the way, read and write the same mask words and store the same pixels
+	const int vlane = lane >> ((tile.lanes >> 16) & 7);
+	const int planeRayIndex = tile.tileInSeg * CVX_WAVE + firstLane + vlane;
+	const bool active = vlane < laneCount && planeRayIndex < S.rayCount;
+	if (vlane < laneCount) {
 		for (int w = 0; w < words; w++) {
-			lds[(w << sshift) + lane] = 0u; // stackalloc is zero-initialised, :208
+			lds[(w << sshift) + vlane] = 0u; // stackalloc is zero-initialised, :208
 		}
 	}
 	const gptr_tile tileOut = (gptr_tile)tile.out;
 #ifdef CVX_EXP_LANE_MAJOR
-	const uint32_t laneByteOff = (uint32_t)(firstLane + lane) * (uint32_t)S.colLen * 4u;
+	const uint32_t laneByteOff = (uint32_t)(firstLane + vlane) * (uint32_t)S.colLen * 4u;
 #else
-	const uint32_t laneByteOff = (uint32_t)(firstLane + lane) * 4u;
+	const uint32_t laneByteOff = (uint32_t)(firstLane + vlane) * 4u;
 #endif
-	uint32_t *seen = lds + lane - (wordBase << sshift);
+	uint32_t *seen = lds + vlane - (wordBase << sshift);
 	ProfLane prof;
 #ifdef CVX_PROFILE_SECTIONS
 	for (int i = 0; i < CVX_NSEC; i++) { prof.acc[i] = 0u; }

@@ -460,6 +460,11 @@ def test_errors_are_reported_not_swallowed():
     fr.camera.PositionY = float("nan")
     with pytest.raises(gpu.CvxError):  # non-finite camera
         ctx.draw_segments(fr, 0)
+    # a world wider than the column loop's packed position (x * 65536 + z, cvx_kernels.h ColumnCursor) is refused at upload
+    import ctypes as C
+    blob = (C.c_uint8 * (65536 * 12))()
+    assert gpu.lib().cvx_world_upload(ctx._h, 0, blob, len(blob), 65536, 2, 1, 65536) == -1  # CVX_ERR_INVALID_ARGUMENT
+    assert b"32768" in gpu.lib().cvx_last_error(ctx._h)
     ctx.close()
 
 

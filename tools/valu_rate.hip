@@ -91,6 +91,59 @@ __global__ __launch_bounds__(64) void k(float *out, float seed, int iters)
 	out[blockIdx.x * 64 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(d0 + d1 + d3 + d4);
 }
 
+__device__ unsigned long long g_clocks[2];
+// the same loop with only the first `active` lanes of every wave alive: does a wave64 instruction cost less when half of the wave is masked off?
+__global__ __launch_bounds__(64) void k_masked(float *out, float seed, int iters, int active, int which)
+{
+	const int lane = threadIdx.x;
+	const bool on = which == 0 ? lane < active : (which == 1 ? lane >= 64 - active : (lane % (64 / active)) == 0); // low lanes / high lanes / spread over the wave
+	if (!on) { return; }
+	const unsigned long long c0 = __builtin_readcyclecounter(), r0 = wall_clock64(); // shader clock counter / constant 100 MHz counter
+	float a0 = seed + lane, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
+	float m = 1.0000001f + seed * 1e-9f, c = 1e-9f + seed;
+	for (int i = 0; i < iters; i++) {
+		asm volatile("v_fma_f32 %0, %8, %9, %0\n v_fma_f32 %1, %8, %9, %1\n v_fma_f32 %2, %8, %9, %2\n v_fma_f32 %3, %8, %9, %3\n"
+		             "v_fma_f32 %4, %8, %9, %4\n v_fma_f32 %5, %8, %9, %5\n v_fma_f32 %6, %8, %9, %6\n v_fma_f32 %7, %8, %9, %7\n"
+		             "v_fma_f32 %0, %8, %9, %0\n v_fma_f32 %1, %8, %9, %1\n v_fma_f32 %2, %8, %9, %2\n v_fma_f32 %3, %8, %9, %3\n"
+		             "v_fma_f32 %4, %8, %9, %4\n v_fma_f32 %5, %8, %9, %5\n v_fma_f32 %6, %8, %9, %6\n v_fma_f32 %7, %8, %9, %7\n"
+		             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+		             : "v"(m), "v"(c));
+	}
+	out[blockIdx.x * 64 + lane] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+	if (blockIdx.x == 0 && lane == (which == 1 ? 63 : 0)) {
+		g_clocks[0] = __builtin_readcyclecounter() - c0;
+		g_clocks[1] = wall_clock64() - r0;
+	}
+}
+
+void run_masked(float *d, int cus, double ghz)
+{
+	const int iters = 20000, instPerIter = 16;
+	const char *names[3] = { "low lanes", "high lanes", "spread" };
+	for (int wavesPerSimd : { 1, 2, 4, 8 })
+	for (int which = 0; which < 3; which += 2) {
+		printf("fma, %d w, %-10s", wavesPerSimd, names[which]);
+		for (int active : { 64, 32, 16, 8, 4, 2, 1 }) {
+			const int blocks = cus * 4 * wavesPerSimd;
+			hipEvent_t e0, e1;
+			(void)hipEventCreate(&e0);
+			(void)hipEventCreate(&e1);
+			hipLaunchKernelGGL(k_masked, dim3(blocks), dim3(64), 0, 0, d, 1.0f, 200, active, which);
+			(void)hipDeviceSynchronize();
+			(void)hipEventRecord(e0);
+			hipLaunchKernelGGL(k_masked, dim3(blocks), dim3(64), 0, 0, d, 1.0f, iters, active, which);
+			(void)hipEventRecord(e1);
+			(void)hipEventSynchronize(e1);
+			float ms = 0;
+			(void)hipEventElapsedTime(&ms, e0, e1);
+			unsigned long long clk[2] = { 0, 0 };
+			(void)hipMemcpyFromSymbol(clk, HIP_SYMBOL(g_clocks), sizeof clk);
+			printf("  %2d lanes: %5.2f (%4.0f MHz)", active, ms * 1e-3 * ghz * 1e9 / ((double)iters * instPerIter * wavesPerSimd), clk[1] ? (double)clk[0] / (double)clk[1] * 100.0 : 0.0);
+		}
+		printf("\n");
+	}
+}
+
 template <int KIND>
 void run(const char *name, float *d, int cus, double ghz)
 {
@@ -127,5 +180,7 @@ int main()
 #define X(name, text) run<K_##name>(#name, d, cus, ghz);
 	BODY_LIST(X)
 #undef X
+	printf("\nactive lanes (4 waves per SIMD): cycles per wave64 v_fma_f32 per SIMD\n");
+	run_masked(d, cus, ghz);
 	return 0;
 }
