@@ -1185,7 +1185,9 @@ __global__ __launch_bounds__(CVX_WAVE, CVX_WAVES_PER_SIMD) void render_kernel(co
 	const int sshift = 31 - __clz(laneCount); // laneCount is a power of two
 	// 2^dupShift physical lanes per ray of a narrow sub-tile (cvx_gpu.hip DrawBatch: a wave with <= 8 active lanes issues ~3.6 x slower); the lanes of a
 	// group hold the same values all the way, read and write the same mask words and store the same pixels
-	const int vlane = lane >> ((tile.lanes >> 16) & 7);
+	const int dupShift = (tile.lanes >> 16) & 7;
+	const int vlane = lane >> dupShift;
+	const bool leader = (lane & ((1 << dupShift) - 1)) == 0; // one lane per ray writes the skybox pixels below (64 stores to one address are not free)
 	const int planeRayIndex = tile.tileInSeg * CVX_WAVE + firstLane + vlane;
 	const bool active = vlane < laneCount && planeRayIndex < S.rayCount;
 	if (vlane < laneCount) {
@@ -1230,7 +1232,7 @@ __global__ __launch_bounds__(CVX_WAVE, CVX_WAVES_PER_SIMD) void render_kernel(co
 	unsigned int skyPixels = 0;
 	for (int w = omin >> 5; w <= (omax >> 5); w++) {
 		uint32_t todo = 0u;
-		if (active) { todo = ~seen[w << sshift] & range_mask(w, omin, omax); }
+		if (active && leader) { todo = ~seen[w << sshift] & range_mask(w, omin, omax); }
 		const int base = w << 5;
 #pragma unroll 4
 		for (int b = 0; b < 32; b++) {
