@@ -99,7 +99,9 @@ int cvx_set_stream(cvx_context *ctx, void *hipStream);
  * (World.cs:278-283), or the exact used length.  columnCount =
  * World.ColumnCount (World.cs:17) = where the element pool starts.
  * The data is copied to the device (and re-laid-out); the caller keeps
- * ownership of storage.  Dimensions must be powers of two (WordBuilder.cs:30).
+ * ownership of storage.  Dimensions must be powers of two (WordBuilder.cs:30),
+ * X and Z at most 32768, Y at most 65536 (8192 x 8192 columns already fill the
+ * 4 GiB of device tables the 32-bit offsets of the kernel address).
  */
 int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byteLength,
                      int dimX, int dimY, int dimZ, int columnCount);
