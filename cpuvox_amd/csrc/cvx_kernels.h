@@ -287,7 +287,7 @@ __device__ __forceinline__ bool dda_step(DDA &d, float farClip) // :135-150
 }
 
 // the same step for the column loop: the position moves in its cursor form (d.px / d.pz / d.sx / d.sz are not touched)
-__device__ __forceinline__ bool dda_step_cursor(DDA &d, ColumnCursor &c, float farClip)
+__device__ __forceinline__ bool dda_step_cursor(DDA &d, ColumnCursor &c, float stopDistance) // true: the distance at which the column loop has to look up (far clip or LOD boundary) is reached
 {
 	const bool stepX = d.tMaxX < d.tMaxZ;
 	const float crossed = stepX ? d.tMaxX : d.tMaxZ;
@@ -298,7 +298,7 @@ __device__ __forceinline__ bool dda_step_cursor(DDA &d, ColumnCursor &c, float f
 	c.rec += (uint32_t)(stepX ? c.recStepX : c.recStepZ);
 	d.distLast = crossed;
 	d.distNext = hw_min(d.tMaxX, d.tMaxZ);
-	return crossed >= farClip;
+	return crossed >= stopDistance;
 }
 
 // ---- CameraData helpers (Assets/Code/Utils/CameraData.cs) ------------------
@@ -1022,7 +1022,9 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 
 	// ONE way out of the column loop (`alive`): every early `return` out of a divergent loop costs the structuriser a flag that is
 	// merged at every join on the way out.
-	bool alive = true;
+	bool alive = true; // false: the ray is finished
+	bool go = true;    // false: out of the column loop -- finished, or at its stop distance (far clip / LOD boundary)
+	float stopDist = m_min(farClip, lodMax);
 	// one column step: `header` / `queue` = the column to process (already fetched), `nextHeader` / `nextQueue` receive the look-ahead
 	auto columnStep = [&](const uint4 &header, const uint4 &queue, uint4 &nextHeader, uint4 &nextQueue, auto guardTag) {
 		constexpr bool GUARD = decltype(guardTag)::value;
@@ -1065,31 +1067,12 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		// next iteration :237-243) and start fetching its record; nothing below touches `ray` again.
 		curDistLast = ray.distLast;
 		curDistNext = ray.distNext;
-		const bool lastColumn = dda_step_cursor(ray, cur, farClip); // true: far clip reached after this column
-		// (the LOD check and the fetch are done for every lane, also one that stops after this column: its state is
-		// dead, and an unconditional load from inside the arena is cheaper than branching around it)
-		// `lod`, `voxelScale`, `L` describe the level of the CURRENT column all through this step -- drawColumn below reads them, there are no
-		// per-step copies of them.  A LOD switch the look-ahead finds for the next column (:237-243) is applied to the DDA and to the cursor at
-		// once, but to those three only at the top of the next step; until then it is marked by lodMax = -infinity, which sends every lane through
-		// the rare branch below once more.
-		if (CVX_RARE(!(ray.distLast < lodMax))) {
-			if (lodMax == -__builtin_inff()) { // the switch found one step ago: this step's column is the first one of the new level
-				lod++;
-				voxelScale *= 2;
-				L = world->level[lod];
-				{ const float next_ = F.lod[min(lod, 5)]; lodMax = lod < 5 ? next_ : __builtin_inff(); }
-			}
-			if (ray.distLast >= lodMax) { // (lod < 5 here: the last level's threshold is +infinity)
-				// back to the DDA's own form of the position (exact for a ray inside the world; one that has just left it is clamped into the table below)
-				ray.px = cur.pos >> 16;
-				ray.pz = cur.pos & 0xFFFF;
-				ray.sx = cur.posStepX >> 16;
-				ray.sz = cur.posStepZ;
-				dda_next_lod(ray, voxelScale, dirXNonNegative, dirZNonNegative);
-				cursor_set(cur, ray, world->level[min(lod + 1, 5)], maskX, maskZ);
-				lodMax = -__builtin_inff();
-			}
-		}
+		// `stopDist` = min(far clip, LOD distance of this level): ONE compare per step serves both (:613 / :273 and :237-243).  A ray that reaches it
+		// leaves the column loop after this column; below the loop it either ends (far clip) or changes level and comes back.  (The record fetched here
+		// for the next column is then the old level's: fetched again after the switch -- twice per ray.)
+		const bool stopReached = dda_step_cursor(ray, cur, stopDist);
+		// (the fetch is done for every lane, also one that stops after this column: its state is dead, and an unconditional load from
+		// inside the arena is cheaper than branching around it)
 		const bool nextOutside = (cur.pos & outsideBits) != 0;
 		const uint32_t rec = cur.rec;
 		nextHeader = ld4(arena, rec);
@@ -1102,7 +1085,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			for (int k = 0; k < 6; k++) { cnt.lod[k] += (lod == k) ? 1u : 0u; }
 		}
 #ifdef CVX_PROFILE_COUNTS
-		const bool sameLod = lodMax != -__builtin_inff(); // (no LOD switch pending for the next column)
+		const bool sameLod = !stopReached; // (no LOD switch before the next column)
 		const bool prevDrawn = lastColumnDrawn, prevClipped = lastColumnClipped;
 		prevDrawnShared = prevDrawn;
 		prevClippedShared = prevClipped;
@@ -1143,16 +1126,39 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 
 		// ---- next column (far clip reached / left the world: WriteSkybox; the step guard never binds on valid input)
 		if (GUARD) { guardSteps--; } // (counted in one of the two copies of the step: the cap is generous by more than a factor of two)
-		alive = alive && !(lastColumn || nextOutside) && (!GUARD || guardSteps > 0);
+		alive = alive && !nextOutside && (!GUARD || guardSteps > 0); // false: the ray is finished (WriteSkybox)
+		go = alive && !stopReached;                                  // false: out of the column loop (finished, far clip, or a LOD boundary)
 		CVX_END(1);
 	};
 	// The loop alternates between two register sets for the record pair, so the look-ahead record never has to be copied into "the
 	// current one" at the end of a step (8 v_mov per step); the code of a step exists twice for it.
-	while (alive) {
-		columnStep(header, queue, headerB, queueB, std::true_type{});
-		if (alive) {
-			columnStep(headerB, queueB, header, queue, std::false_type{});
+	for (;;) {
+		while (go) {
+			columnStep(header, queue, headerB, queueB, std::true_type{});
+			if (go) {
+				columnStep(headerB, queueB, header, queue, std::false_type{});
+			}
 		}
+		// NextLOD (:237-243) for the column the ray stands on, if that is why it left the loop: alive, at or beyond this level's LOD distance, not
+		// beyond far clip (the last level's distance is +infinity: lod < 5 here)
+		if (!(alive && ray.distLast >= lodMax && !(ray.distLast >= farClip))) {
+			break;
+		}
+		// back to the DDA's own form of the position (exact: the ray is inside the world)
+		ray.px = cur.pos >> 16;
+		ray.pz = cur.pos & 0xFFFF;
+		ray.sx = cur.posStepX >> 16;
+		ray.sz = cur.posStepZ;
+		dda_next_lod(ray, voxelScale, dirXNonNegative, dirZNonNegative);
+		lod++;
+		voxelScale *= 2;
+		L = world->level[lod];
+		{ const float next_ = F.lod[min(lod, 5)]; lodMax = lod < 5 ? next_ : __builtin_inff(); }
+		stopDist = m_min(farClip, lodMax);
+		cursor_set(cur, ray, L, maskX, maskZ);
+		header = ld4(arena, cur.rec);
+		queue = ld4(arena, cur.rec + 16u);
+		go = true;
 	}
 }
 
