@@ -1024,7 +1024,20 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 	// merged at every join on the way out.
 	bool alive = true; // false: the ray is finished
 	bool go = true;    // false: out of the column loop -- finished, or at its stop distance (far clip / LOD boundary)
-	float stopDist = m_min(farClip, lodMax);
+	// The world's edge is the third thing the stop distance stands for: the DDA leaves the world with the crossing number n of an axis, n = cells
+	// between the ray and the edge, at distance tMax + (n - 1) * tDelta up to the rounding of its additions; three crossings short of that the ray
+	// is certainly still inside, so the column loop needs no position test ((p & dimensionMask) != p, :613 / World.cs:130-142) below that distance.
+	// Beyond it the loop is left after EVERY column and the exact test is made below the loop (the last few columns of a ray).
+	auto edgeDistance = [&]() -> float {
+		const int px = cur.pos >> 16, pz = cur.pos & 0xFFFF;
+		const int sx = cur.posStepX, sz = cur.posStepZ;
+		const int nx = sx > 0 ? (dimX - px) >> lod : (px >> lod) + 1, nz = sz > 0 ? (dimZ - pz) >> lod : (pz >> lod) + 1;
+		const float ex = sx != 0 ? ray.tMaxX + (float)(nx - 4) * ray.tDeltaX : __builtin_inff();
+		const float ez = sz != 0 ? ray.tMaxZ + (float)(nz - 4) * ray.tDeltaZ : __builtin_inff();
+		return m_min(ex, ez);
+	};
+	bool nearEdge = false; // beyond edgeDistance(): every column comes up for the exact test
+	float stopDist = m_min(m_min(farClip, lodMax), edgeDistance());
 	// one column step: `header` / `queue` = the column to process (already fetched), `nextHeader` / `nextQueue` receive the look-ahead
 	auto columnStep = [&](const uint4 &header, const uint4 &queue, uint4 &nextHeader, uint4 &nextQueue, auto guardTag) {
 		constexpr bool GUARD = decltype(guardTag)::value;
@@ -1073,7 +1086,6 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		const bool stopReached = dda_step_cursor(ray, cur, stopDist);
 		// (the fetch is done for every lane, also one that stops after this column: its state is dead, and an unconditional load from
 		// inside the arena is cheaper than branching around it)
-		const bool nextOutside = (cur.pos & outsideBits) != 0;
 		const uint32_t rec = cur.rec;
 		nextHeader = ld4(arena, rec);
 		nextQueue = ld4(arena, rec + 16u);
@@ -1126,7 +1138,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 
 		// ---- next column (far clip reached / left the world: WriteSkybox; the step guard never binds on valid input)
 		if (GUARD) { guardSteps--; } // (counted in one of the two copies of the step: the cap is generous by more than a factor of two)
-		alive = alive && !nextOutside && (!GUARD || guardSteps > 0); // false: the ray is finished (WriteSkybox)
+		alive = alive && (!GUARD || guardSteps > 0); // false: the ray is finished (WriteSkybox)
 		go = alive && !stopReached;                                  // false: out of the column loop (finished, far clip, or a LOD boundary)
 		CVX_END(1);
 	};
@@ -1141,8 +1153,18 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		}
 		// NextLOD (:237-243) for the column the ray stands on, if that is why it left the loop: alive, at or beyond this level's LOD distance, not
 		// beyond far clip (the last level's distance is +infinity: lod < 5 here)
-		if (!(alive && ray.distLast >= lodMax && !(ray.distLast >= farClip))) {
-			break;
+		if (!alive || ray.distLast >= farClip || (cur.pos & outsideBits) != 0) {
+			break; // finished: window closed / frustum left the world / step guard, far clip (:273), left the world (:613)
+		}
+		if (!(ray.distLast >= lodMax)) {
+			// neither: the ray is within a few columns of the world's edge.  From here on it comes up after every column (stopDist below every
+			// distance); the record of the column it stands on was fetched into the other register pair: fetched again (a handful of times per ray)
+			nearEdge = true;
+			stopDist = -__builtin_inff();
+			header = ld4(arena, cur.rec);
+			queue = ld4(arena, cur.rec + 16u);
+			go = true;
+			continue;
 		}
 		// back to the DDA's own form of the position (exact: the ray is inside the world)
 		ray.px = cur.pos >> 16;
@@ -1154,8 +1176,8 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		voxelScale *= 2;
 		L = world->level[lod];
 		{ const float next_ = F.lod[min(lod, 5)]; lodMax = lod < 5 ? next_ : __builtin_inff(); }
-		stopDist = m_min(farClip, lodMax);
 		cursor_set(cur, ray, L, maskX, maskZ);
+		stopDist = nearEdge ? -__builtin_inff() : m_min(m_min(farClip, lodMax), edgeDistance());
 		header = ld4(arena, cur.rec);
 		queue = ld4(arena, cur.rec + 16u);
 		go = true;
