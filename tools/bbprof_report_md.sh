@@ -54,7 +54,7 @@ L_ld=ln('__device__ __forceinline__ uint4 ld4('); L_st=ln('void st_pixel('); L_r
 L_dda=ln('bool dda_step('); L_scan=ln('int scan_up('); L_scan_end=ln('bits of word w that fall')
 L_walk=ln('// ---- element loop, :424-611'); L_portion=ln('const float portionBottom = '); L_side=ln('// side of the run, :484-542')
 L_sidepix=ln('// pixel loop :519-533'); L_sidepix_end=ln('CVX_END(5);'); L_facepix=ln('// :595-603'); L_facepix_end=ln('CVX_END(7);')
-L_step=ln('auto columnStep = '); L_step_end=ln('while (alive) {')
+L_step=ln('auto columnStep = '); L_step_end=ln('while (go) {')
 def what(w,loc):
     if loc is None or loc==0: return "compiler-placed (join)"
     if L_ld<=loc<=L_ld+2 or L_rec-1<=loc<=L_rec+5 or L_step<=loc<=L_step_end or L_dda<=loc<=L_dda+20: return "record of the column now being processed (its two loads were issued one step earlier as the look-ahead)" if 'vmcnt' in w else ""
