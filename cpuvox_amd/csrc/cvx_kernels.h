@@ -290,7 +290,9 @@ __device__ __forceinline__ bool dda_step(DDA &d, float farClip) // :135-150
 __device__ __forceinline__ bool dda_step_cursor(DDA &d, ColumnCursor &c, float stopDistance) // true: the distance at which the column loop has to look up (far clip or LOD boundary) is reached
 {
 	const bool stepX = d.tMaxX < d.tMaxZ;
-	const float crossed = stepX ? d.tMaxX : d.tMaxZ;
+	// the distance crossed is the smaller tMax (:139, :145) -- which is what distNext already holds: every place that sets tMax sets distNext to the
+	// minimum of the two (here, dda_init, dda_next_lod, dda_step_to_world_intersection; tMax values are positive sums, so min and "x < z ? x : z" agree)
+	const float crossed = d.distNext;
 	const float nextX = d.tMaxX + d.tDeltaX, nextZ = d.tMaxZ + d.tDeltaZ;
 	d.tMaxX = stepX ? nextX : d.tMaxX;
 	d.tMaxZ = stepX ? d.tMaxZ : nextZ;
@@ -1112,10 +1114,11 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 				const bool cull = ((int)((header.z >> 16) != 0u) & (int)(frustumDirMaxWorld != CVX_FLOAT_EPSILON)) != 0;
 				const float columnWorldMin = (float)(header.y >> 16);
 				const float columnWorldMax = (float)(header.z & 0xFFFFu);
-				const float distTop = frustumDirMaxWorld > 0.0f ? curDistNext : curDistLast;
-				const float distBot = frustumDirMinWorld < 0.0f ? curDistNext : curDistLast;
-				const float newMax = posY + frustumDirMaxWorld * distTop;
-				const float newMin = posY + frustumDirMinWorld * distBot;
+				// :264-269: the upper bound at the farther distance when the direction rises, at the nearer one otherwise (the lower bound likewise) -- written
+				// as the larger / smaller of the two products (curDistNext >= curDistLast >= 0 and rounding is monotone, so the product the reference
+				// selects IS the larger / smaller one): a max / min instead of a compare + select, same value
+				const float newMax = posY + hw_max(frustumDirMaxWorld * curDistNext, frustumDirMaxWorld * curDistLast);
+				const float newMin = posY + hw_min(frustumDirMinWorld * curDistNext, frustumDirMinWorld * curDistLast);
 				const bool leftWorld = ((int)cull & ((int)(newMin > worldBoundsMax) | (int)(newMax < worldBoundsMin))) != 0; // frustum left the world entirely
 				const bool noOverlap = ((int)cull & ((int)(columnWorldMin > newMax) | (int)(columnWorldMax < newMin))) != 0; // this column does not overlap the writable world bounds
 				const bool narrowed = ((int)cull & (int)!leftWorld & (int)!noOverlap) != 0;
