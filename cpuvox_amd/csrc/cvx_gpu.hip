@@ -170,7 +170,7 @@ float EstimateTileCost(const cvx_context *ctx, const DevFrame &F, const DevSegme
 // placements: optional caller-chosen output address per tile (canonical order: frame-major, segment-major); 0 = this
 // context does not render the tile.  placeCursor runs over the whole batch.
 int BuildFrame(cvx_context *ctx, const cvx_segment_data segments[4], const cvx_camera_data *camera, int W, int H, const float vp[2],
-               int bufferIndex, int frameIndex, DevFrame &F, std::vector<DevTile> &tiles, LastDraw &last,
+               int bufferIndex, int frameIndex, DevFrame &F, std::vector<DevTile> &tiles, std::vector<float> &tileCost, std::vector<int> &tileWords, LastDraw &last,
                const uint64_t *placements, int64_t placementCount, int64_t &placeCursor)
 {
 	if (!Finite(camera->WorldToScreenMatrix, 16) || !Finite(camera->PositionXZ, 2) || !Finite(&camera->PositionY, 1) ||
@@ -251,8 +251,8 @@ int BuildFrame(cvx_context *ctx, const cvx_segment_data segments[4], const cvx_c
 				out = (s < 2 ? F.poolTD : F.poolLR) + ((size_t)(S.tileBase + t) * (size_t)S.colLen) * CVX_WAVE;
 			}
 			tiles.push_back(DevTile{ frameIndex, s, t, 0, out });
-			ctx->hostTileCost.push_back(EstimateTileCost(ctx, F, S, t));
-			ctx->hostTileWords.push_back(maskWords);
+			tileCost.push_back(EstimateTileCost(ctx, F, S, t));
+			tileWords.push_back(maskWords);
 		}
 	}
 	// reference capacity check: TopDown holds W+2H rays, LeftRight 2W+H
@@ -663,7 +663,7 @@ int DrawBatch(cvx_context *ctx, int frameCount, const cvx_segment_data *segments
 	for (int f = 0; f < frameCount; f++) {
 		int b = placements ? 0 : (firstBufferIndex + f) % ctx->bufferCount;
 		rc = BuildFrame(ctx, segments + (size_t)f * 4, cameras + f, screenWidth, screenHeight, vanishingPoints + (size_t)f * 2, b, f,
-		                ctx->hostFrames[(size_t)f], ctx->hostTiles, placements ? placedScratch : ctx->last[(size_t)b],
+		                ctx->hostFrames[(size_t)f], ctx->hostTiles, ctx->hostTileCost, ctx->hostTileWords, placements ? placedScratch : ctx->last[(size_t)b],
 		                placements, placementCount, placeCursor);
 		if (rc != CVX_OK) { return rc; }
 	}
@@ -696,7 +696,33 @@ int DrawBatch(cvx_context *ctx, int frameCount, const cvx_segment_data *segments
 		}
 #endif
 		const std::vector<float> &cost = ctx->hostTileCost;
-		std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+		// descending by cost, ties in tile order (a stable sort): estimates are non-negative floats, whose bit patterns order like their values, so four
+		// stable counting passes over the inverted bits do it (30 000 tiles of a 512-frame batch: the host part of the draw call 2.8 -> 1.2 ms against std::stable_sort with an indirect compare; four threads for the frame descriptors on top were slower than one)
+		bool radix = n >= 2048;
+		for (size_t i = 0; i < n && radix; i++) { radix = cost[i] >= 0.0f; } // (a negative or NaN estimate: the general sort)
+		if (radix) {
+			std::vector<uint32_t> keys(n), other(n), keys2(n);
+			for (size_t i = 0; i < n; i++) {
+				uint32_t bits;
+				std::memcpy(&bits, &cost[i], 4);
+				keys[i] = ~(bits == 0x80000000u ? 0u : bits); // (-0 orders with +0)
+			}
+			for (int pass = 0; pass < 4; pass++) {
+				size_t count[257] = { 0 };
+				const int shift = pass * 8;
+				for (size_t i = 0; i < n; i++) { count[((keys[i] >> shift) & 0xFFu) + 1]++; }
+				for (int b = 0; b < 256; b++) { count[b + 1] += count[b]; }
+				for (size_t i = 0; i < n; i++) {
+					const size_t at = count[(keys[i] >> shift) & 0xFFu]++;
+					keys2[at] = keys[i];
+					other[at] = order[i];
+				}
+				keys.swap(keys2);
+				order.swap(other);
+			}
+		} else {
+			std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
+		}
 #ifdef CVX_EXPERIMENTS
 		if (const char *v = std::getenv("CVX_TILE_ORDER")) { // diagnostics: how much the launch order matters
 			if (!std::strcmp(v, "reverse")) {
