@@ -556,14 +556,6 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 	float curDistLast, curDistNext;   // ray.IntersectionDistances of the current column
 	unsigned int consumed = 0u;       // counting variant: elements the reference's walk has dereferenced in this column
 	float worldBoundsMin, worldBoundsMax;
-#ifdef CVX_PROFILE_COUNTS
-	// carry-over census: lastColumnDrawn = the previous DDA step of this lane ran drawColumn at the same LOD, so its
-	// camSpace*Next are this column's camSpace*Last; lastClipMin / lastClipMax = frustum bounds of a clip the previous step computed
-	bool lastColumnDrawn = false, lastColumnClipped = false;
-	float lastClipMin = 0.0f, lastClipMax = 0.0f;
-	bool thisColumnClipped = false;
-	bool prevDrawnShared = false, prevClippedShared = false; // the two flags as they were when the current column started
-#endif
 
 	// Clip, element walk and pixel writes of ExecuteRay (:289-611) for the current column;
 	// false = the ray is finished (every such exit is WriteSkybox).
@@ -579,26 +571,9 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		const f3 camSpaceMaxNext = f3_madd(planeStartTop, planeDir, curDistNext);
 
 		CVX_COUNT(8);
-#ifdef CVX_PROFILE_COUNTS
-		if (__ballot(!prevDrawnShared) == 0ull) { CVX_COUNT(13); } // every lane entering could take camSpace*Last from the previous column
-		thisColumnClipped = false;
-#endif
 		bool windowClosed = false; // :399-403: the clipped column lies outside the free pixel window -> the ray is finished
 		if (curDistLast > 2.0f && frustumDirMaxWorld == CVX_FLOAT_EPSILON) { // :295-422
 			CVX_COUNT(2);
-#ifdef CVX_PROFILE_COUNTS
-			{
-				const bool hit = prevClippedShared && lastClipMin == frustumBoundsMin && lastClipMax == frustumBoundsMax;
-				const bool hitMax = prevClippedShared && lastClipMax == frustumBoundsMax;
-				if (__ballot(!hit) == 0ull) { CVX_COUNT(14); }    // every clipping lane could reuse the whole Last half
-				if (__ballot(!hitMax) == 0ull) { CVX_COUNT(15); } // ... at least what depends on frustumBoundsMax only
-				if (hit) { prof.lanes[14]++; }
-				if (hitMax) { prof.lanes[15]++; }
-				thisColumnClipped = true;
-				lastClipMin = frustumBoundsMin;
-				lastClipMax = frustumBoundsMax;
-			}
-#endif
 			float clipLastMinLerp, clipLastMaxLerp, clipNextMinLerp, clipNextMaxLerp;
 			// CameraData.cs:103,111.  frustumBounds = (integer pixel in [-1, 16385]) -/+ 0.501: magnitude in [0.499, 16386], always "safe"
 			const float invFrustumMin = quot_safe(1.0f, recip_safe(frustumBoundsMin)), invFrustumMax = quot_safe(1.0f, recip_safe(frustumBoundsMax));
@@ -1046,38 +1021,6 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		CVX_BEGIN();
 		CVX_WAITPROBE(9);
 		CVX_COUNT(1);
-#ifdef CVX_EXP_EXTRA_VALU /* sensitivity experiment: N extra vector instructions per column step (results unchanged) */
-		{
-			float pad_ = curDistLast;
-#pragma unroll
-			for (int k_ = 0; k_ < CVX_EXP_EXTRA_VALU; k_++) { asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(pad_)); }
-			asm volatile("" ::"v"(pad_));
-		}
-#endif
-#ifdef CVX_EXP_EXTRA_PK /* ... N extra packed-f32 instructions per column step */
-		{
-			double pad2_ = (double)curDistLast;
-#pragma unroll
-			for (int k_ = 0; k_ < CVX_EXP_EXTRA_PK; k_++) { asm volatile("v_pk_add_f32 %0, %0, %0" : "+v"(pad2_)); }
-			asm volatile("" ::"v"(pad2_));
-		}
-#endif
-#ifdef CVX_EXP_EXTRA_SLOW /* ... N extra half-rate vector instructions (v_max_f32) per column step */
-		{
-			float pad3_ = curDistLast;
-#pragma unroll
-			for (int k_ = 0; k_ < CVX_EXP_EXTRA_SLOW; k_++) { asm volatile("v_max_f32 %0, %0, %0" : "+v"(pad3_)); }
-			asm volatile("" ::"v"(pad3_));
-		}
-#endif
-#ifdef CVX_EXP_EXTRA_SALU /* ... N extra scalar instructions per column step */
-		{
-			int spad_ = 0;
-#pragma unroll
-			for (int k_ = 0; k_ < CVX_EXP_EXTRA_SALU; k_++) { asm volatile("s_add_u32 %0, %0, 1" : "+s"(spad_)::"scc"); }
-			asm volatile("" ::"s"(spad_));
-		}
-#endif
 		// ---- look ahead: move the DDA to the next column (Step :613 / :252 / :273, then the LOD check of the
 		// next iteration :237-243) and start fetching its record; nothing below touches `ray` again.
 		curDistLast = ray.distLast;
@@ -1098,14 +1041,6 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 #pragma unroll
 			for (int k = 0; k < 6; k++) { cnt.lod[k] += (lod == k) ? 1u : 0u; }
 		}
-#ifdef CVX_PROFILE_COUNTS
-		const bool sameLod = !stopReached; // (no LOD switch before the next column)
-		const bool prevDrawn = lastColumnDrawn, prevClipped = lastColumnClipped;
-		prevDrawnShared = prevDrawn;
-		prevClippedShared = prevClipped;
-		lastColumnDrawn = false; // an empty or culled column breaks the chain
-		lastColumnClipped = false;
-#endif
 		{
 			bool draw = true;
 			worldBoundsMin = 0.0f;
@@ -1131,10 +1066,6 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			if (draw) {
 				alive = drawColumn(header, queue);
 				if (COUNT) { cnt.E += consumed; }
-#ifdef CVX_PROFILE_COUNTS
-				lastColumnDrawn = sameLod;
-				lastColumnClipped = sameLod && thisColumnClipped;
-#endif
 			}
 			CVX_BEGIN();
 		}
