@@ -578,6 +578,7 @@ def main():
                 "frames": 1, "ms": round(dt / K * 1e3, 4), "fps": round(K / dt, 1), "mrays": round(rays1 / dt / 1e6, 3),
                 "kernel_ms": round(k_ms1 / max(1, n1), 4),
                 "ms_max": round(per_frame[worst] * 1e3, 4), "fps_min": round(1.0 / per_frame[worst], 1), "worst_pose": (worst * POSE_STRIDE) % POSES,
+                "ms_p95": round(sorted(per_frame)[min(K - 1, (95 * K) // 100)] * 1e3, 4),  # (ms_max is one wall-clock sample: a host hiccup shows up there)
                 "pipelined_2deep": {"ms": round(dt2 / K * 1e3, 4), "fps": round(K / dt2, 1), "mrays": round(rays1 / dt2 / 1e6, 3)},
                 "what": f"{K} single-frame cvx_draw_segments calls (first {K} poses of the bench), blocking / 2-deep CVX_DRAW_ASYNC over two raybuffer pairs; wall clock",
             }
