@@ -418,22 +418,47 @@ int Launch(cvx_context *ctx, int frameCount, int flags)
 	if (rc != CVX_OK) { return rc; }
 	CVX_HIP(ctx, hipEventRecord(evStart, ctx->stream));
 	if (nTiles) {
-		// One launch for the whole batch: the iteration direction (RenderJob.Execute :174-178) is a wave-uniform
-		// runtime switch inside the kernel, so the tails of different frames overlap.  LDS = the widest seen-mask any
-		// tile of the batch needs.  (Splitting the batch into concurrent launches by LDS need was measured and lost:
-		// launches that share a hardware queue serialise, and more than ~10 resident waves per CU add nothing.)
-		const size_t ldsBytes = (size_t)std::max(ctx->ldsWordsNeeded, ctx->minMaskWords * CVX_WAVE) * sizeof(uint32_t);
-		dim3 grid((unsigned)nTiles), block(CVX_WAVE);
-		if (ctx->countersEnabled) {
-			hipLaunchKernelGGL((cvxk::render_kernel<true>), grid, block, ldsBytes, ctx->stream, ctx->devFrames, ctx->devTiles, ctx->devWorld, ctx->devCounters);
-#ifdef CVX_EXPERIMENTS
-		} else if (ctx->renderStateMachine) {
-			hipLaunchKernelGGL(cvxk::render_sm_kernel, grid, block, ldsBytes, ctx->stream, ctx->devFrames, ctx->devTiles, ctx->devWorld, cvxk::SmParams{ ctx->smThreshold });
-#endif
-		} else {
-			hipLaunchKernelGGL((cvxk::render_kernel<false>), grid, block, ldsBytes, ctx->stream, ctx->devFrames, ctx->devTiles, ctx->devWorld, ctx->devCounters);
+		// One launch per LDS class (DrawBatch), all frames of the batch in it: the iteration direction (RenderJob.Execute :174-178) is a wave-uniform
+		// runtime switch inside the kernel, so the tails of different frames overlap.  A launch has ONE dynamic-LDS size, the largest mask any of its
+		// waves needs; the classes run beside each other on streams of their own (workgroups of different launches share a CU), forked from and joined
+		// to ctx->stream by events, so the draw is still one unit of work on the caller's stream and the event pair around it times all of it.
+		int active = 0;
+		for (int c = 0; c < cvx_context::kLaunchClasses; c++) { active += ctx->launchClass[c].count ? 1 : 0; }
+		if (active > 1) {
+			if (!ctx->classFork) { CVX_HIP(ctx, hipEventCreateWithFlags(&ctx->classFork, hipEventDisableTiming)); }
+			CVX_HIP(ctx, hipEventRecord(ctx->classFork, ctx->stream));
 		}
-		CVX_HIP(ctx, hipGetLastError());
+		int used = 0; // the first class with waves runs on ctx->stream itself
+		for (int c = 0; c < cvx_context::kLaunchClasses; c++) {
+			const cvx_context::LaunchClass &lc = ctx->launchClass[c];
+			if (!lc.count) { continue; }
+			hipStream_t stream = ctx->stream;
+			if (used > 0) {
+				hipStream_t &aux = ctx->classStream[used - 1];
+				if (!aux) { CVX_HIP(ctx, hipStreamCreateWithFlags(&aux, hipStreamNonBlocking)); }
+				if (!ctx->classJoin[used - 1]) { CVX_HIP(ctx, hipEventCreateWithFlags(&ctx->classJoin[used - 1], hipEventDisableTiming)); }
+				CVX_HIP(ctx, hipStreamWaitEvent(aux, ctx->classFork, 0));
+				stream = aux;
+			}
+			const size_t ldsBytes = (size_t)std::max(lc.ldsWords, ctx->minMaskWords * CVX_WAVE) * sizeof(uint32_t);
+			const DevTile *tiles = ctx->devTiles + lc.first;
+			dim3 grid((unsigned)lc.count), block(CVX_WAVE);
+			if (ctx->countersEnabled) {
+				hipLaunchKernelGGL((cvxk::render_kernel<true>), grid, block, ldsBytes, stream, ctx->devFrames, tiles, ctx->devWorld, ctx->devCounters);
+#ifdef CVX_EXPERIMENTS
+			} else if (ctx->renderStateMachine) {
+				hipLaunchKernelGGL(cvxk::render_sm_kernel, grid, block, ldsBytes, stream, ctx->devFrames, tiles, ctx->devWorld, cvxk::SmParams{ ctx->smThreshold });
+#endif
+			} else {
+				hipLaunchKernelGGL((cvxk::render_kernel<false>), grid, block, ldsBytes, stream, ctx->devFrames, tiles, ctx->devWorld, ctx->devCounters);
+			}
+			CVX_HIP(ctx, hipGetLastError());
+			if (used > 0) {
+				CVX_HIP(ctx, hipEventRecord(ctx->classJoin[used - 1], stream));
+				CVX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->classJoin[used - 1], 0));
+			}
+			used++;
+		}
 	}
 	CVX_HIP(ctx, hipEventRecord(evStop, ctx->stream));
 	if (!(flags & CVX_DRAW_ASYNC)) {
@@ -756,58 +781,94 @@ int DrawBatch(cvx_context *ctx, int frameCount, const cvx_segment_data *segments
 		// fitted to the sweeps in profiles/r02_occupancy.md: a wave of 64 / 32 / 16 / 8 ... lanes costs 1 / 0.68 / 0.40 / 0.25 ... of
 		// a full one, and throughput grows with (resident waves)^0.4 (at most 16 per CU: 128 VGPRs).  1080p picks 10 KB (every
 		// top / bottom tile stays whole), 4K picks 17 KB (68-word top / bottom tiles whole, left / right tiles halved).
-		int budget = ctx->maxWaveMaskWords;
-		if (ctx->maxWaveMaskWordsAuto) {
-			static const int candidates[] = { 40 * CVX_WAVE, 48 * CVX_WAVE, 60 * CVX_WAVE, 68 * CVX_WAVE, 80 * CVX_WAVE, 96 * CVX_WAVE, 120 * CVX_WAVE, 160 * CVX_WAVE, 256 * CVX_WAVE, 512 * CVX_WAVE };
-			static const double laneCost[7] = { 1.0, 0.68, 0.40, 0.25, 0.16, 0.11, 0.08 }; // 64, 32, 16, 8, 4, 2, 1 lanes
-			double best = 0.0;
-			for (int candidate : candidates) {
-				const int resident = std::min(16, (int)(163840 / ((size_t)candidate * 4)));
-				if (resident < 1) { continue; }
-				double work = 0.0;
-				for (size_t i = 0; i < n; i++) {
-					int s2 = split, level = 0;
-					while ((1 << level) < s2) { level++; }
-					while (s2 < CVX_WAVE && ctx->hostTileWords[i] * (CVX_WAVE / s2) > candidate) { s2 *= 2; level++; }
-					work += (double)s2 * laneCost[level];
+		// Round 4: the choice is made PER TILE and the waves are grouped into LDS classes, each class its own launch on its own stream (Launch).  Before, a
+		// launch had one LDS size -- the largest wave's -- so at 4K a 68-word top / bottom tile put 17 KB on every wave of the draw (9 resident waves per
+		// CU) although half the tiles of a frame with its vanishing point on the screen need 34 words or fewer.  Same cost model as before (a wave of
+		// 64 / 32 / 16 / 8 ... lanes costs 1 / 0.68 / 0.40 / 0.25 ... of a full one; throughput grows with (resident waves)^0.4, at most 16 per CU), applied
+		// to the tile alone: cut it into 2^k waves where k minimises (waves x lane cost) / (waves of that size a CU holds)^0.4.
+		static const double laneCost[7] = { 1.0, 0.68, 0.40, 0.25, 0.16, 0.11, 0.08 }; // 64, 32, 16, 8, 4, 2, 1 lanes
+		static const int classLimit[cvx_context::kLaunchClasses] = { 40 * CVX_WAVE, 68 * CVX_WAVE, 1 << 30 }; // 10 KB (16 waves per CU), 17 KB (9), the rest
+		auto residentWaves = [](int waveWords) { return std::max(1, std::min(16, (int)(163840 / ((size_t)waveWords * 4)))); };
+		int baseLevel = 0;
+		while ((1 << baseLevel) < split) { baseLevel++; }
+		const int budget = ctx->maxWaveMaskWords; // (diagnostics: CVX_MAX_WAVE_MASK_WORDS pins one budget for every tile, as in rounds 2 and 3)
+		std::vector<DevTile> classTiles[cvx_context::kLaunchClasses];
+		int classWords[cvx_context::kLaunchClasses] = { 1, 1, 1 };
+#ifdef CVX_TILE_TIMES
+		std::vector<uint32_t> classSource[cvx_context::kLaunchClasses];
+		g_sourceTiles = n;
+#endif
+		for (size_t i = 0; i < n; i++) {
+			DevTile t = ctx->hostTiles[order[i]];
+			const int words = ctx->hostTileWords[order[i]];
+			int tileSplit = split;
+			if (ctx->maxWaveMaskWordsAuto) {
+				double best = 0.0;
+				for (int s2 = split, level = baseLevel; s2 <= CVX_WAVE; s2 *= 2, level++) {
+					const int waveWords = words * (CVX_WAVE / s2);
+					if ((size_t)waveWords * 4 > 65536 && s2 < CVX_WAVE) { continue; } // (the dynamic-LDS limit of a launch without an opt-in attribute)
+					const double cost = (double)(s2 / split) * laneCost[level] / std::pow((double)residentWaves(waveWords), 0.4);
+					if (best == 0.0 || cost < best * 0.999) { best = cost; tileSplit = s2; }
 				}
-				const double cost = work / std::pow((double)resident, 0.4);
-				if (best == 0.0 || cost < best) { best = cost; budget = candidate; }
+			} else {
+				while (tileSplit < CVX_WAVE && words * (CVX_WAVE / tileSplit) > budget) { tileSplit *= 2; }
+			}
+			const int lanesPerWave = CVX_WAVE / tileSplit;
+			int cls = 0;
+#ifndef CVX_EXP_ONE_LDS_CLASS
+			while (cls + 1 < cvx_context::kLaunchClasses && words * lanesPerWave > classLimit[cls]) { cls++; }
+#endif
+			classWords[cls] = std::max(classWords[cls], words * lanesPerWave);
+			if (tileSplit == 1) {
+				classTiles[cls].push_back(t);
+#ifdef CVX_TILE_TIMES
+				classSource[cls].push_back(order[i]);
+#endif
+				continue;
+			}
+			for (int k = 0; k < tileSplit; k++) {
+				// A wave with 8 or fewer active lanes issues vector instructions ~3.6 x slower than one with 16 (tools/valu_rate.hip, gfx950),
+				// so the rays of a narrow sub-tile are worked on by 64 / laneCount
+				// lanes each: same addresses, same values, same stores from every lane of a group (not with the counters on: they are summed over lanes).
+				int dupShift = 0;
+				while (!ctx->countersEnabled && (lanesPerWave << dupShift) < CVX_WAVE) { dupShift++; }
+				t.lanes = (k * lanesPerWave) | (lanesPerWave << 8) | (dupShift << 16);
+				classTiles[cls].push_back(t);
+#ifdef CVX_TILE_TIMES
+				classSource[cls].push_back(order[i]);
+#endif
+			}
+		}
+		// A class with only a handful of waves is not worth a launch of its own: folded into the next larger one
+		for (int c = 0; c + 1 < cvx_context::kLaunchClasses; c++) {
+			int next = c + 1;
+			while (next + 1 < cvx_context::kLaunchClasses && classTiles[next].empty()) { next++; }
+			if (!classTiles[c].empty() && !classTiles[next].empty() && classTiles[c].size() < 256) {
+				// (merged in LPT order: both lists are sorted by descending cost; merge by walking the original order is not kept per class, so append and
+				// let the few short waves of the small class run at the end)
+				classTiles[next].insert(classTiles[next].end(), classTiles[c].begin(), classTiles[c].end());
+				classWords[next] = std::max(classWords[next], classWords[c]);
+#ifdef CVX_TILE_TIMES
+				classSource[next].insert(classSource[next].end(), classSource[c].begin(), classSource[c].end());
+#endif
+				classTiles[c].clear();
 			}
 		}
 		std::vector<DevTile> sorted;
 		sorted.reserve(n * (size_t)split);
 #ifdef CVX_TILE_TIMES
 		g_waveSource.clear();
-		g_sourceTiles = n;
 #endif
 		int ldsWords = 1; // words * lanes of the largest wave
-		for (size_t i = 0; i < n; i++) {
-			DevTile t = ctx->hostTiles[order[i]];
-			const int words = ctx->hostTileWords[order[i]];
-			int tileSplit = split;
-			while (tileSplit < CVX_WAVE && words * (CVX_WAVE / tileSplit) > budget) { tileSplit *= 2; }
-			const int lanesPerWave = CVX_WAVE / tileSplit;
-			ldsWords = std::max(ldsWords, words * lanesPerWave);
-			if (tileSplit == 1) {
-				sorted.push_back(t);
+		for (int c = 0; c < cvx_context::kLaunchClasses; c++) {
+			ctx->launchClass[c].first = sorted.size();
+			ctx->launchClass[c].count = classTiles[c].size();
+			ctx->launchClass[c].ldsWords = classWords[c];
+			sorted.insert(sorted.end(), classTiles[c].begin(), classTiles[c].end());
 #ifdef CVX_TILE_TIMES
-				g_waveSource.push_back(order[i]);
+			g_waveSource.insert(g_waveSource.end(), classSource[c].begin(), classSource[c].end());
 #endif
-				continue;
-			}
-			for (int k = 0; k < tileSplit; k++) {
-				// A wave with 8 or fewer active lanes issues vector instructions ~3.6 x slower than one with 16 (tools/valu_rate.hip, gfx950: 11.8 against
-				// 3.2 cycles per instruction and SIMD, whatever the number of resident waves), so the rays of a narrow sub-tile are worked on by 16 / laneCount
-				// lanes each: same addresses, same values, same stores from every lane of a group (not with the counters on: they are summed over lanes).
-				int dupShift = 0;
-				while (!ctx->countersEnabled && (lanesPerWave << dupShift) < CVX_WAVE) { dupShift++; }
-				t.lanes = (k * lanesPerWave) | (lanesPerWave << 8) | (dupShift << 16);
-				sorted.push_back(t);
-#ifdef CVX_TILE_TIMES
-				g_waveSource.push_back(order[i]);
-#endif
-			}
+			if (!classTiles[c].empty()) { ldsWords = std::max(ldsWords, classWords[c]); }
 		}
 		ctx->ldsWordsNeeded = ldsWords;
 		ctx->hostTiles.swap(sorted);

@@ -144,7 +144,7 @@ int main()
 		CK(hipEventRecord(e0));                                                                                                            \
 		hipLaunchKernelGGL((cal_gather<BYTES, PER_LINE>), dim3(blocks), dim3(256), 0, 0, TABLE, lines - 1u, rounds, 0x2545F491u, out);      \
 		CK(hipEventRecord(e1));                                                                                                            \
-		report("cal_gather<" #BYTES "," #PER_LINE ">" TAG, TBYTES, (double)records *BYTES, (double)records, timed(e0, e1));                \
+		report("cal_gather<" #BYTES ";" #PER_LINE ">" TAG, TBYTES, (double)records *BYTES, (double)records, timed(e0, e1));                \
 	}
 	GATHER(32, 1, small_, smallBytes, "_134MB")
 	GATHER(32, 4, small_, smallBytes, "_134MB")

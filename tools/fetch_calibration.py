@@ -21,10 +21,10 @@ def main():
                 d = int(row["Dispatch_Id"])
                 rows[d][row["Counter_Name"]] += float(row["Counter_Value"])
                 names[d] = row["Kernel_Name"]
-        order = sorted(rows)
-        measured = order[1::2]  # every second dispatch is a measured kernel
+        order = [d for d in sorted(rows) if "cal_" in names[d]]  # (hipMemset's fill kernels are dispatches too)
+        measured = order[1::2]  # every second dispatch is a measured kernel, the one before it the cache flush
         if len(measured) != len(plain):
-            print(f"<!-- {path}: {len(order)} dispatches, expected {2 * len(plain)} -->")
+            print(f"<!-- {path}: {len(order)} dispatches, expected {2 * len(plain)} of cal_* -->")
             continue
         for k, d in enumerate(measured):
             for c, v in rows[d].items():

@@ -25,7 +25,7 @@
 #include <vector>
 
 struct WaveRec {
-	unsigned long long cycles, real;
+	unsigned long long t0, t1, real;
 	unsigned hwid, xcc;
 };
 
@@ -78,6 +78,21 @@ struct WaveRec {
 	X(cnd_vcc_by_salu, "s_and_b64 vcc, exec, s[22:23]\n", T2(L8("v_cndmask_b32 ", ", %8, %9, vcc")))                            \
 	X(cnd_vcc_stale, "", T2(L8("v_cndmask_b32 ", ", %8, %9, vcc")))                                                             \
 	X(cnd_sgpr_stale, "", T2(L8("v_cndmask_b32_e64 ", ", %8, %9, s[24:25]")))                                                   \
+	X(cmp_cnd3, "", "v_cmp_lt_f32 vcc, %8, %0\n v_cndmask_b32 %0, %8, %9, vcc\n v_cndmask_b32 %1, %8, %9, vcc\n v_cndmask_b32 %2, %8, %9, vcc\n" \
+	                "v_cmp_lt_f32 vcc, %8, %3\n v_cndmask_b32 %3, %8, %9, vcc\n v_cndmask_b32 %4, %8, %9, vcc\n v_cndmask_b32 %5, %8, %9, vcc\n" \
+	                "v_cmp_lt_f32 vcc, %8, %6\n v_cndmask_b32 %6, %8, %9, vcc\n v_cndmask_b32 %7, %8, %9, vcc\n v_cndmask_b32 %0, %8, %9, vcc\n" \
+	                "v_cmp_lt_f32 vcc, %8, %1\n v_cndmask_b32 %1, %8, %9, vcc\n v_cndmask_b32 %2, %8, %9, vcc\n v_cndmask_b32 %3, %8, %9, vcc\n") \
+	X(cmp_add_cnd, "", "v_cmp_lt_f32 vcc, %8, %0\n v_add_f32 %4, %8, %4\n v_cndmask_b32 %0, %8, %9, vcc\n v_add_f32 %5, %8, %5\n" \
+	                   "v_cmp_lt_f32 vcc, %8, %1\n v_add_f32 %6, %8, %6\n v_cndmask_b32 %1, %8, %9, vcc\n v_add_f32 %7, %8, %7\n" \
+	                   "v_cmp_lt_f32 vcc, %8, %2\n v_add_f32 %4, %8, %4\n v_cndmask_b32 %2, %8, %9, vcc\n v_add_f32 %5, %8, %5\n" \
+	                   "v_cmp_lt_f32 vcc, %8, %3\n v_add_f32 %6, %8, %6\n v_cndmask_b32 %3, %8, %9, vcc\n v_add_f32 %7, %8, %7\n") \
+	X(cnd_e64_vcc, "v_cmp_lt_f32 vcc, %8, %9\n", T2(L8("v_cndmask_b32_e64 ", ", %8, %9, vcc")))                                \
+	X(cnd_vcc_dst_src, "v_cmp_lt_f32 vcc, %8, %9\n", T2(D8("v_cndmask_b32 ", ", %8, ") ))   /* (vcc implied) */                \
+	X(cnd_vcc_add_mix, "v_cmp_lt_f32 vcc, %8, %9\n", "v_cndmask_b32 %0, %8, %9, vcc\n v_add_f32 %4, %8, %4\n v_cndmask_b32 %1, %8, %9, vcc\n v_add_f32 %5, %8, %5\n" \
+	                   "v_cndmask_b32 %2, %8, %9, vcc\n v_add_f32 %6, %8, %6\n v_cndmask_b32 %3, %8, %9, vcc\n v_add_f32 %7, %8, %7\n" \
+	                   "v_cndmask_b32 %0, %8, %9, vcc\n v_add_f32 %4, %8, %4\n v_cndmask_b32 %1, %8, %9, vcc\n v_add_f32 %5, %8, %5\n" \
+	                   "v_cndmask_b32 %2, %8, %9, vcc\n v_add_f32 %6, %8, %6\n v_cndmask_b32 %3, %8, %9, vcc\n v_add_f32 %7, %8, %7\n") \
+	X(addc_vcc, "v_cmp_lt_f32 vcc, %8, %9\n", T2(L8("v_addc_co_u32 ", ", vcc, %8, %9, vcc")))                                        \
 	/* a fresh mask for every select: compare + select pairs, and s_and + select pairs (what `a & b ? x : y` compiles to) */    \
 	X(cmp_cnd_pairs, "", "v_cmp_lt_f32 vcc, %8, %0\n v_cndmask_b32 %0, %8, %9, vcc\n v_cmp_lt_f32 vcc, %8, %1\n v_cndmask_b32 %1, %8, %9, vcc\n" \
 	                     "v_cmp_lt_f32 vcc, %8, %2\n v_cndmask_b32 %2, %8, %9, vcc\n v_cmp_lt_f32 vcc, %8, %3\n v_cndmask_b32 %3, %8, %9, vcc\n" \
@@ -157,7 +172,7 @@ __global__ __launch_bounds__(1024) void k(WaveRec *recs, float *out, float seed,
 	if (KIND == K_##name) {                                                                                                       \
 		asm volatile(pre text text text text : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)     \
 		             : "v"(m), "v"(c)                                                                                             \
-		             : "vcc", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");                                             \
+		                          : "vcc", "scc", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");                                      \
 	}
 			BODY_LIST(X)
 #undef X
@@ -167,7 +182,8 @@ __global__ __launch_bounds__(1024) void k(WaveRec *recs, float *out, float seed,
 			unsigned hwid, xcc;
 			asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n s_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hwid), "=s"(xcc));
 			WaveRec r;
-			r.cycles = t1 - t0;
+			r.t0 = t0;
+			r.t1 = t1;
 			r.real = r1 - r0;
 			r.hwid = hwid;
 			r.xcc = xcc;
@@ -207,19 +223,29 @@ Result run(const char *pre, const char *text, WaveRec *dRecs, float *dOut, int c
 	if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed: %s\n", hipGetErrorString(hipGetLastError())); return { 0, 0, 0, 0 }; }
 	std::vector<WaveRec> recs(waves);
 	(void)hipMemcpy(recs.data(), dRecs, sizeof(WaveRec) * (size_t)waves, hipMemcpyDeviceToHost);
-	std::map<unsigned, int> perSimd;
+	// per SIMD: the span from its first wave's start to its last wave's end (the waves of a SIMD do not share it evenly: the oldest
+	// is served first, so one wave's own loop time says little); reported: the median SIMD's span / instructions of all its waves
+	struct Simd { int waves = 0; unsigned long long first = ~0ull, last = 0; };
+	std::map<unsigned, Simd> perSimd;
 	std::vector<double> cyc, mhz;
 	for (const WaveRec &r : recs) {
-		perSimd[(r.xcc & 0xF) << 16 | (r.hwid & 0xFF30)]++; // se, sh, cu, simd (pipe and wave slot masked out)
-		cyc.push_back((double)r.cycles);
-		mhz.push_back(r.real ? (double)r.cycles / (double)r.real * 100.0 : 0.0);
+		Simd &sd = perSimd[(r.xcc & 0xF) << 16 | (r.hwid & 0xFF30)]; // se, sh, cu, simd (pipe and wave slot masked out)
+		sd.waves++;
+		sd.first = std::min(sd.first, r.t0);
+		sd.last = std::max(sd.last, r.t1);
+		mhz.push_back(r.real ? (double)(r.t1 - r.t0) / (double)r.real * 100.0 : 0.0);
+	}
+	int lo = 1 << 30, hi = 0;
+	for (auto &kv : perSimd) {
+		lo = std::min(lo, kv.second.waves);
+		hi = std::max(hi, kv.second.waves);
+		cyc.push_back((double)(kv.second.last - kv.second.first) / kv.second.waves);
 	}
 	std::sort(cyc.begin(), cyc.end());
 	std::sort(mhz.begin(), mhz.end());
-	int lo = 1 << 30, hi = 0;
-	for (auto &kv : perSimd) { lo = std::min(lo, kv.second); hi = std::max(hi, kv.second); }
 	const double inst = (double)iters * instructionsPerTrip(pre, text);
-	return { cyc[cyc.size() / 2] / inst / wavesPerSimd, mhz[mhz.size() / 2], lo, hi };
+	(void)wavesPerSimd;
+	return { cyc[cyc.size() / 2] / inst, mhz[mhz.size() / 2], lo, hi };
 }
 
 int main(int argc, char **argv)
