@@ -117,8 +117,6 @@ struct cvx_context {
 	int forcedSplit = 0;                       // CVX_TILE_SPLIT=1|2|...|64 (diagnostics): fixed split factor
 	float tileCostPixelWeight = 0.f;           // launch-order estimate += weight * pixels of the tile's window (CVX_TILE_COST_PIXELS, diagnostics)
 	bool tileCostMiddleRay = false;            // CVX_TILE_COST_MIDDLE_RAY=1 (diagnostics): estimate from the tile's middle ray instead of its longer edge ray
-	bool renderStateMachine = false;           // CVX_RENDER_SM=1 (experiment, profiles/r02_experiments.md): render_sm_kernel instead of render_kernel<false>
-	int smThreshold = 0;                       // CVX_SM_THRESHOLD (diagnostics): one threshold for every block of the state machine
 	int minMaskWords = 0;                      // CVX_MIN_MASK_WORDS (diagnostics): lower bound of the LDS mask words per lane, i.e. an occupancy cap
 };
 

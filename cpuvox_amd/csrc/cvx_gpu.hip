@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "cvx_context.h"
+#include "cpuvox_gpu_diag.h"
 #include "cvx_kernels.h"
 
 namespace {
@@ -445,10 +446,6 @@ int Launch(cvx_context *ctx, int frameCount, int flags)
 			dim3 grid((unsigned)lc.count), block(CVX_WAVE);
 			if (ctx->countersEnabled) {
 				hipLaunchKernelGGL((cvxk::render_kernel<true>), grid, block, ldsBytes, stream, ctx->devFrames, tiles, ctx->devWorld, ctx->devCounters);
-#ifdef CVX_EXPERIMENTS
-			} else if (ctx->renderStateMachine) {
-				hipLaunchKernelGGL(cvxk::render_sm_kernel, grid, block, ldsBytes, stream, ctx->devFrames, tiles, ctx->devWorld, cvxk::SmParams{ ctx->smThreshold });
-#endif
 			} else {
 				hipLaunchKernelGGL((cvxk::render_kernel<false>), grid, block, ldsBytes, stream, ctx->devFrames, tiles, ctx->devWorld, ctx->devCounters);
 			}
@@ -529,11 +526,6 @@ int cvx_create(int device, cvx_context **out)
 		if (const char *v = std::getenv("CVX_TILE_COST_PIXELS")) { // diagnostics
 			const float w = (float)std::atof(v);
 			if (w >= 0.f && w <= 100.f) { ctx->tileCostPixelWeight = w; }
-		}
-		if (const char *v = std::getenv("CVX_RENDER_SM")) { ctx->renderStateMachine = std::atoi(v) != 0; }
-		if (const char *v = std::getenv("CVX_SM_THRESHOLD")) {
-			const int t = std::atoi(v);
-			if (t >= 1 && t <= 64) { ctx->smThreshold = t; }
 		}
 		if (const char *v = std::getenv("CVX_MIN_MASK_WORDS")) {
 			const int w = std::atoi(v);
@@ -791,7 +783,28 @@ int DrawBatch(cvx_context *ctx, int frameCount, const cvx_segment_data *segments
 		auto residentWaves = [](int waveWords) { return std::max(1, std::min(16, (int)(163840 / ((size_t)waveWords * 4)))); };
 		int baseLevel = 0;
 		while ((1 << baseLevel) < split) { baseLevel++; }
-		const int budget = ctx->maxWaveMaskWords; // (diagnostics: CVX_MAX_WAVE_MASK_WORDS pins one budget for every tile, as in rounds 2 and 3)
+		// The split itself follows ONE budget per draw, chosen as in rounds 2 and 3 by the single-size model over these candidates (1080p: 10 KB, every top /
+		// bottom tile whole, the few wider left / right tiles halved; 4K: 17 KB): choosing per tile -- which keeps a 41..60-word left / right tile whole in a
+		// 15 KB class -- measured 3.6 % slower at 1080p (r04_experiments.md: such a wave is the longest-lived of the draw, and a draw is not over before its
+		// longest wave), and with a launch of its own for those tiles 26 % slower.
+		int budget = ctx->maxWaveMaskWords; // (diagnostics: CVX_MAX_WAVE_MASK_WORDS pins it)
+#ifndef CVX_EXP_PER_TILE_RULE
+		if (ctx->maxWaveMaskWordsAuto) {
+			static const int candidates[] = { 40 * CVX_WAVE, 48 * CVX_WAVE, 60 * CVX_WAVE, 68 * CVX_WAVE, 80 * CVX_WAVE, 96 * CVX_WAVE, 120 * CVX_WAVE, 160 * CVX_WAVE, 256 * CVX_WAVE };
+			double bestCost = 0.0;
+			for (int candidate : candidates) {
+				const int resident = residentWaves(candidate);
+				double work = 0.0;
+				for (size_t i = 0; i < n; i++) {
+					int s2 = split, level = baseLevel;
+					while (s2 < CVX_WAVE && ctx->hostTileWords[i] * (CVX_WAVE / s2) > candidate) { s2 *= 2; level++; }
+					work += (double)s2 * laneCost[level];
+				}
+				const double cost = work / std::pow((double)resident, 0.4);
+				if (bestCost == 0.0 || cost < bestCost) { bestCost = cost; budget = candidate; }
+			}
+		}
+#endif
 		std::vector<DevTile> classTiles[cvx_context::kLaunchClasses];
 		int classWords[cvx_context::kLaunchClasses] = { 1, 1, 1 };
 #ifdef CVX_TILE_TIMES
@@ -802,7 +815,11 @@ int DrawBatch(cvx_context *ctx, int frameCount, const cvx_segment_data *segments
 			DevTile t = ctx->hostTiles[order[i]];
 			const int words = ctx->hostTileWords[order[i]];
 			int tileSplit = split;
+#ifdef CVX_EXP_PER_TILE_RULE /* A/B partner: the split chosen per tile (measured slower, see above) */
 			if (ctx->maxWaveMaskWordsAuto) {
+#else
+			if (false) {
+#endif
 				double best = 0.0;
 				for (int s2 = split, level = baseLevel; s2 <= CVX_WAVE; s2 *= 2, level++) {
 					const int waveWords = words * (CVX_WAVE / s2);
@@ -1325,6 +1342,7 @@ int cvx_copy_rows(cvx_context *ctx, void *hipStream, int toPacked, int64_t spanC
 	return CVX_OK;
 }
 
+#if defined(CVX_EXPERIMENTS) || defined(CVX_PROFILE_SECTIONS) /* include/cpuvox_gpu_diag.h: not in the product library */
 int cvx_debug_occupancy(cvx_context *ctx, int64_t ldsBytes, int *blocksPerCU)
 {
 	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
@@ -1339,7 +1357,7 @@ int cvx_debug_section_cycles(cvx_context *ctx, uint64_t out[32], int reset)
 {
 	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
 	if (!out) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "out is NULL"); }
-#if defined(CVX_PROFILE_SECTIONS) || defined(CVX_SM_STATS)
+#if defined(CVX_PROFILE_SECTIONS)
 	CVX_HIP(ctx, hipSetDevice(ctx->device));
 	CVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	unsigned long long tmp[32];
@@ -1400,5 +1418,6 @@ int cvx_selftest_math(cvx_context *ctx, int op, int n, const float *a, const flo
 	(void)hipFree(d);
 	return rc;
 }
+#endif /* diagnostics */
 
 } // extern "C"

@@ -157,7 +157,9 @@ __device__ __forceinline__ f3 f3_lerp(f3 a, f3 b, float t) { return { a.x + (b.x
 #define CVX_RARE(x) (x)
 #define CVX_USUAL(x) (x)
 #endif
-// non-short-circuit boolean algebra on lane masks (one s_and / s_or each; `&&` / `||` / `?:` between lane masks can become divergent branches)
+// boolean algebra on lane masks in clip_world_bounds.  Written with `&&` / `||` on purpose: for these flags (every operand a plain compare result, no side
+// effect to guard) the compiler turns the short-circuit forms into one s_and_b64 / s_or_b64 each -- the same code `&` / `|` on the converted
+// ints give, measured (r03_experiments.md: -0.8 %); what must be avoided between lane masks is `?:`, which became a divergent branch.
 #define CVX_AND(a, b) ((a) && (b))
 #define CVX_OR(a, b) ((a) || (b))
 #define CVX_FLOAT_EPSILON 1.401298464324817e-45f /* C# float.Epsilon (denormal), DrawSegmentRayJob.cs:220 */
@@ -332,8 +334,8 @@ __device__ __forceinline__ bool clip_world_bounds(f3 pMin, f3 pMax, float fMin, 
 	const bool a2 = pMax.x > pMax.z * fMax;
 	const bool b1 = pMin.x < pMin.z * fMin;
 	const bool b2 = pMax.x < pMax.z * fMin;
-	// (the flag algebra with `&` / `|` on purpose: `&&` / `?:` on lane masks are compiled into divergent branches, a handful of scalar
-	// instructions each, to compute one bit)
+	// (CVX_AND / CVX_OR, never `?:` between flags: a ternary of two lane masks is compiled into a divergent branch -- saveexec, a handful of
+	// scalar instructions, restore -- to compute one bit)
 	const bool n1 = !a1, n2 = !a2;
 	straddles = CVX_AND(CVX_AND(n1, b1), a2);
 	const bool needMin = CVX_OR(a1, b1);
@@ -1066,6 +1068,15 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			if (draw) {
 				alive = drawColumn(header, queue);
 				if (COUNT) { cnt.E += consumed; }
+#ifndef CVX_EXP_NO_DRAIN
+				// Every vector-memory operation of the drawn column is complete from here on.  Without this the compiler does not know what the pixel loops left in
+				// flight (a colour load whose pixel loop never ran, stores) when the paths of a drawn and a skipped column join below, and drains the queue
+				// there with s_waitcnt vmcnt(0) -- in EVERY step, also a skipped column's, whose only pending loads are the look-ahead record issued ~30
+				// instructions earlier: the one-step look-ahead was being waited for in the step that issued it (rounds 1-3).  With the drain on the drawn
+				// path only (where a colour load, being younger, has waited for the look-ahead anyway), the join knows that nothing but the look-ahead can
+				// be pending and the wait for it moves to its first use, the top of the next step.
+				__builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0), expcnt / lgkmcnt untouched (gfx9 encoding)
+#endif
 			}
 			CVX_BEGIN();
 		}
@@ -1242,9 +1253,6 @@ __global__ __launch_bounds__(CVX_WAVE, CVX_WAVES_PER_SIMD) void render_kernel(co
 }
 
 } // namespace cvxk
-#ifdef CVX_EXPERIMENTS /* `make gpu-exp`: the state-machine render kernel of round 2 (slower; kept as the record of that experiment) */
-#include "cvx_render_sm.h"
-#endif
 namespace cvxk {
 
 // ---------------------------------------------------------------------------
@@ -1605,6 +1613,7 @@ __global__ __launch_bounds__(64) void image_gather_kernel(const ImageFrame *__re
 	}
 }
 
+#if defined(CVX_EXPERIMENTS) || defined(CVX_PROFILE_SECTIONS) /* include/cpuvox_gpu_diag.h */
 // ---------------------------------------------------------------------------
 // arithmetic self-test (cvx_selftest_math): pins the device float contract.
 // ---------------------------------------------------------------------------
@@ -1637,5 +1646,7 @@ __global__ void selftest_math_kernel(int op, int n, const float *__restrict__ a,
 	}
 	out[i] = r;
 }
+
+#endif
 
 } // namespace cvxk

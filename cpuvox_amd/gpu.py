@@ -28,13 +28,15 @@ EXPORTS = [
     "cvx_set_buffer_count", "cvx_draw_segments", "cvx_draw_segments_batch", "cvx_set_shard", "cvx_synchronize",
     "cvx_clear_raybuffer", "cvx_read_raybuffer", "cvx_blit_segments", "cvx_blit_segments_batch", "cvx_raybuffer_device_ptr",
     "cvx_screen_device_ptr", "cvx_last_draw_ms", "cvx_enable_counters", "cvx_get_counters",
-    "cvx_get_raybuffer_layout", "cvx_selftest_math", "cvx_version", "cvx_bind_raybuffers", "cvx_draw_time_stats", "cvx_debug_section_cycles", "cvx_debug_occupancy", "cvx_copy_rows", "cvx_draw_segments_placed",
-    "cvx_world_downsample", "cvx_world_build_lods", "cvx_free", "cvx_debug_section_histogram",
+    "cvx_get_raybuffer_layout", "cvx_version", "cvx_bind_raybuffers", "cvx_draw_time_stats", "cvx_copy_rows", "cvx_draw_segments_placed",
+    "cvx_world_downsample", "cvx_world_build_lods", "cvx_free",
     "cvx_shard_plan_create", "cvx_shard_plan_destroy", "cvx_shard_plan_tile_count", "cvx_shard_plan_sections", "cvx_shard_plan_tile_out", "cvx_shard_plan_transfer",
     "cvx_comm_unique_id", "cvx_comm_create", "cvx_comm_create_timeout", "cvx_comm_destroy", "cvx_exchange",
     "cvx_image_plan_create", "cvx_image_plan_destroy", "cvx_image_plan_tile_count", "cvx_image_plan_sizes", "cvx_image_plan_transfer",
     "cvx_image_plan_tile_out", "cvx_image_pack", "cvx_image_exchange", "cvx_image_unpack",
 ]
+# include/cpuvox_gpu_diag.h: only the experiment / profiling builds export these (cpuvox_amd.gpu.use_library(".../libcpuvox_gpu_exp.so"))
+DIAG_EXPORTS = ["cvx_selftest_math", "cvx_debug_occupancy", "cvx_debug_section_cycles", "cvx_debug_section_histogram"]
 
 
 class Counters(C.Structure):
@@ -128,8 +130,11 @@ def _bind(path: str) -> C.CDLL:
         L.cvx_get_raybuffer_layout.argtypes = [C.c_void_p, C.c_int, C.POINTER(RaybufferLayout)]
         L.cvx_bind_raybuffers.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
         L.cvx_copy_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
-        L.cvx_debug_section_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
-        L.cvx_selftest_math.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        if hasattr(L, "cvx_selftest_math"):  # a diagnostics build (include/cpuvox_gpu_diag.h)
+            L.cvx_debug_section_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
+            L.cvx_debug_section_histogram.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
+            L.cvx_debug_occupancy.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int)]
+            L.cvx_selftest_math.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.cvx_world_downsample.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_float)]
         L.cvx_world_build_lods.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -369,30 +374,37 @@ class Context:
         self._check(lib().cvx_get_raybuffer_layout(self._h, which, C.byref(out)))
         return out
 
+    @staticmethod
+    def _diag(name: str):
+        """An entry point of include/cpuvox_gpu_diag.h: present in the experiment / profiling builds only."""
+        if not hasattr(lib(), name):
+            raise RuntimeError(f"{name} is a diagnostic of libcpuvox_gpu_exp.so / the profiling builds (include/cpuvox_gpu_diag.h); "
+                               "the product library does not export it: cpuvox_amd.gpu.use_library(<diagnostics build>) first")
+        return getattr(lib(), name)
+
     def debug_occupancy(self, lds_bytes: int) -> int:
         n = C.c_int()
-        lib().cvx_debug_occupancy.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int)]
+        self._diag("cvx_debug_occupancy")
         self._check(lib().cvx_debug_occupancy(self._h, lds_bytes, C.byref(n)))
         return n.value
 
     def debug_section_cycles(self, reset: bool = False):
-        """Diagnostic build only: wave cycles per render-kernel section (include/cpuvox_gpu.h)."""
+        """Diagnostic build only: wave cycles per render-kernel section (include/cpuvox_gpu_diag.h)."""
         out = (C.c_uint64 * 32)()
-        self._check(lib().cvx_debug_section_cycles(self._h, out, int(reset)))
+        self._check(self._diag("cvx_debug_section_cycles")(self._h, out, int(reset)))
         return list(out)
 
     def debug_section_histogram(self, reset: bool = False):
-        """Counting diagnostic build only: [section][bucket of 8 lanes] executions (include/cpuvox_gpu.h)."""
+        """Counting diagnostic build only: [section][bucket of 8 lanes] executions (include/cpuvox_gpu_diag.h)."""
         out = (C.c_uint64 * 128)()
-        lib().cvx_debug_section_histogram.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
-        self._check(lib().cvx_debug_section_histogram(self._h, out, int(reset)))
+        self._check(self._diag("cvx_debug_section_histogram")(self._h, out, int(reset)))
         return [list(out[i * 8:(i + 1) * 8]) for i in range(16)]
 
     def selftest_math(self, op: int, a: np.ndarray, b: np.ndarray) -> np.ndarray:
         a = np.ascontiguousarray(a, dtype=np.float32)
         b = np.ascontiguousarray(b, dtype=np.float32)
         out = np.empty_like(a)
-        self._check(lib().cvx_selftest_math(self._h, op, a.size, a.ctypes.data, b.ctypes.data, out.ctypes.data))
+        self._check(self._diag("cvx_selftest_math")(self._h, op, a.size, a.ctypes.data, b.ctypes.data, out.ctypes.data))
         return out
 
 

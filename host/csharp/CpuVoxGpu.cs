@@ -94,10 +94,6 @@ namespace CpuVox.Gpu
 		[DllImport(Lib)] public static extern int cvx_draw_segments_placed(IntPtr ctx, int frameCount, SegmentData* segments, CameraData* cameras, int screenWidth, int screenHeight, float* vanishingPoints, long tileCount, ulong* tileOut, int flags);
 		[DllImport(Lib)] public static extern int cvx_get_raybuffer_layout(IntPtr ctx, int which, out RaybufferLayout layout);
 		[DllImport(Lib)] public static extern int cvx_copy_rows(IntPtr ctx, IntPtr hipStream, int toPacked, long spanCount, RowSpan* spansDevice, void* packedDevice);
-		[DllImport(Lib)] public static extern int cvx_selftest_math(IntPtr ctx, int op, int n, float* a, float* b, float* result);
-		[DllImport(Lib)] public static extern int cvx_debug_occupancy(IntPtr ctx, long ldsBytes, out int blocksPerCU);
-		[DllImport(Lib)] public static extern int cvx_debug_section_cycles(IntPtr ctx, ulong* out32, int reset);
-		[DllImport(Lib)] public static extern int cvx_debug_section_histogram(IntPtr ctx, ulong* out128, int reset);
 		// multi-GPU: shard plan (host arithmetic), library-owned RCCL communicator, tile exchange (RenderManager.cs:358-363 sharded)
 		[DllImport(Lib)] public static extern int cvx_shard_plan_create(int frameCount, SegmentData* segments, float* vanishingPoints, int screenWidth, int screenHeight, int rank, int worldSize, out IntPtr plan);
 		[DllImport(Lib)] public static extern void cvx_shard_plan_destroy(IntPtr plan);

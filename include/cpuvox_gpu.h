@@ -290,18 +290,6 @@ typedef struct cvx_raybuffer_layout {
 } cvx_raybuffer_layout;
 int cvx_get_raybuffer_layout(cvx_context *ctx, int which, cvx_raybuffer_layout *out);
 
-/* Resident render-kernel workgroups (= waves) per CU the runtime predicts for a given dynamic LDS size. */
-int cvx_debug_occupancy(cvx_context *ctx, int64_t ldsBytes, int *blocksPerCU);
-
-/* Diagnostic build only (make gpu-prof, -DCVX_PROFILE_SECTIONS): wave cycles spent per code section of the
- * render kernel (s_memtime stamps), accumulated over all launches.  Sections: 0 prologue/epilogue, 1 phase A
- * (DDA step + header + cull), 2 frustum clip, 3 element walk, 4 side-face setup, 5 side-face pixels,
- * 6 top/bottom setup, 7 top/bottom pixels, 8 skybox pass.  The regular build returns CVX_ERR_NOT_READY. */
-int cvx_debug_section_cycles(cvx_context *ctx, uint64_t out[32], int reset); /* [16+i] = cycles/16 * active lanes of section i */
-/* Counting diagnostic build only (make gpu-count): how many lanes were active each time a wave executed section i:
- * out[i * 8 + b] = executions with 8b+1 .. 8b+8 active lanes. */
-int cvx_debug_section_histogram(cvx_context *ctx, uint64_t out[128], int reset);
-
 /* World.DownSample(extraLods) (Assets/Code/World.cs:45-127: DownSampleColumn :71-96, DownSamplePartial :101-127, with
  * RLEColumnBuilder.ToFinalColumn WordBuilder.cs:181-268 and the RLEColumn constructor World.cs:190-234) as a device
  * kernel: builds LOD extraLods from the LOD 0 blob (same layout as cvx_world_upload takes; `lod` must be 0 -- the reference only
@@ -318,11 +306,6 @@ int cvx_world_downsample(cvx_context *ctx, const void *storage, int64_t byteLeng
 int cvx_world_build_lods(cvx_context *ctx, const void *storage, int64_t byteLength, int dimX, int dimY, int dimZ, int columnCount, int levelCount,
                          void **outStorage, int64_t *outByteLength, int32_t *outColumnCount, float *outDeviceMs);
 void cvx_free(void *p);
-
-/* Arithmetic self-test hook used by tests: evaluates op on n float pairs on
- * the device.  op: 0 a/b, 1 sqrt(a), 2 1/sqrt(a), 3 a*b+c style lerp a+b*(b-a),
- * 4 floor, 5 ceil, 6 round-half-even, 7 (int)a with the x86 rule. */
-int cvx_selftest_math(cvx_context *ctx, int op, int n, const float *a, const float *b, float *out);
 
 const char *cvx_version(void);
 

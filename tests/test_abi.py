@@ -26,6 +26,23 @@ def test_gpu_library_exports_every_declared_symbol():
     assert b"gfx950" in L.cvx_version()
 
 
+def test_product_abi_has_no_diagnostic_entry_points():
+    """The drop-in boundary is include/cpuvox_gpu.h; section profiles, the occupancy query and the arithmetic self-test live in
+    include/cpuvox_gpu_diag.h and in the experiment / profiling builds only."""
+    header = open(os.path.join(ROOT, "include", "cpuvox_gpu.h")).read()
+    assert "debug" not in header.lower() and "selftest" not in header.lower()
+    diag = _declared("cpuvox_gpu_diag.h", "cvx_")
+    assert sorted(gpu.DIAG_EXPORTS) == diag
+    L = gpu.lib()
+    assert not [n for n in diag if hasattr(L, n)], "the product library exports diagnostics"
+    data = open(os.path.join(ROOT, "cpuvox_amd", "libcpuvox_gpu.so"), "rb").read()
+    assert b"cvx_debug" not in data and b"selftest" not in data
+    exp = os.path.join(ROOT, "cpuvox_amd", "libcpuvox_gpu_exp.so")
+    if os.path.exists(exp):
+        E = C.CDLL(exp)
+        assert not [n for n in diag + _declared("cpuvox_gpu.h", "cvx_") if not hasattr(E, n)], "the experiment build exports the product ABI plus the diagnostics"
+
+
 def test_host_library_exports_every_declared_symbol():
     L = host.lib()
     declared = _declared("cpuvox_host.h", "cvxh_")

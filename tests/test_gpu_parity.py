@@ -302,31 +302,6 @@ def test_launch_order_is_invisible(order, exp_library):
         ctx.close()
 
 
-@pytest.mark.parametrize("threshold", [0, 1, 64])
-def test_state_machine_kernel_is_bit_exact(threshold, exp_library):
-    monkeypatch = exp_library
-    """CVX_RENDER_SM=1 selects render_sm_kernel (cvx_render_sm.h): the same per-ray arithmetic, but the wave schedules the blocks of
-    ExecuteRay per lane instead of walking all rays column by column.  An experiment (slower, profiles/r02_experiments.md) kept
-    behind the switch; its pixels must not depend on the schedule: default thresholds, every non-empty block per pass (1),
-    fullest block only (64)."""
-    monkeypatch.setenv("CVX_RENDER_SM", "1")
-    if threshold:
-        monkeypatch.setenv("CVX_SM_THRESHOLD", str(threshold))
-    ctx = gpu.Context(0)
-    try:
-        for name in ("mill256_t0", "mill512_t075_1080p", "proc256_t04_lod8", "proc256_t075_lod8"):
-            if name not in scenes.SCENES:
-                continue
-            ws, fr, W, H = scenes.scene_frame(name)
-            ctx.upload_world(ws)
-            ctx.set_resolution(W, H)
-            g_td, g_lr = _render_gpu(ctx, fr)
-            o_td, o_lr, _ = O.draw_segments(ws, fr, W, H, clear=CLEAR)
-            _compare(f"{name} state machine T={threshold}", fr, g_td, g_lr, o_td, o_lr)
-    finally:
-        ctx.close()
-
-
 def test_cpp_example_on_the_c_abis(tmp_path):
     """examples/flythrough.cpp: world building, camera, the RenderManager twin and the GPU library used from plain C++ through
     the two C ABIs (no Python in the loop); the image it writes for path key t = 0 equals the Python-driven render of the same pose."""
@@ -358,9 +333,18 @@ def test_cpp_example_on_the_c_abis(tmp_path):
     assert np.array_equal(rgb, want)
 
 
-def test_device_float_contract(contexts):
+@pytest.fixture
+def diag_context(exp_library):
+    """A context of the experiment build: cvx_selftest_math (include/cpuvox_gpu_diag.h) is not in the product library.  Same sources, same
+    compiler flags, same device functions (cvx_kernels.h) as the product build."""
+    ctx = gpu.Context(0)
+    yield ctx
+    ctx.close()
+
+
+def test_device_float_contract(diag_context):
     """IEEE binary32 on the device: correctly rounded / and sqrt, no contraction, denormals kept, x86 (int) rule."""
-    ctx = contexts("proc256", 320, 200)
+    ctx = diag_context
     rng = np.random.default_rng(7)
     n = 1 << 16
     a = rng.standard_normal(n).astype(np.float32) * np.float32(10.0) ** rng.integers(-20, 20, n).astype(np.float32)
@@ -400,11 +384,11 @@ def _float_soup(rng, n):
     return x
 
 
-def test_short_division_is_ieee_division(contexts):
+def test_short_division_is_ieee_division(diag_context):
     """quot_safe / recip_safe (the division without v_div_scale / v_div_fmas / v_div_fixup that the side-face and frustum blocks use
     for operands in [2^-30, 2^30]) against IEEE division on 2^28 operand pairs -- random bit patterns, renderer-range values, all
     specials, all-ones mantissas (the hard case of a Newton-refined reciprocal) -- and the helpers' other contracts."""
-    ctx = contexts("proc256", 320, 200)
+    ctx = diag_context
     rng = np.random.default_rng(2026)
     n = 1 << 24
     hard = ((rng.integers(0, 254, 4096).astype(np.uint32) << 23) | np.uint32(0x7FFFFF)).view(np.float32)  # 1.11...1 x 2^e
