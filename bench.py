@@ -477,24 +477,32 @@ def main():
         args.pmc_csv = find_counter_summary(args)
     if args.pmc_csv:
         # Counter summary of a rocprofv3 --pmc run of THIS command and build (tools/pmc_passes.sh + tools/pmc_aggregate.py); never a
-        # committed file of another build.  rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KiB per dispatch (fabric requests of the L2,
-        # MI355X_MICROARCH.md "HBM").  The guide's gfx950 rule: FETCH_SIZE counts a wide coalesced read at half its bytes (x2); this
-        # kernel's loads are scattered 16-byte accesses, uncalibrated -- both readings are given, `traffic` is the raw sum.
+        # committed file of another build.  `traffic` = bytes the L2 exchanged with the fabric (Infinity Cache / HBM) per launch, calibrated
+        # (profiles/r04_fetch_calibration.md, tools/fetch_calibration.hip): on gfx950 EVERY read request of the L2 is a 128-byte line, also for a
+        # scattered 4-, 16- or 32-byte access, and FETCH_SIZE tallies each at 64 bytes -- so fetched bytes = 128 x TCC_EA0_RDREQ_128B + 64 x (the
+        # 64-byte requests) + 32 x TCC_EA0_RDREQ_32B when the summary holds those counters, else 2 x FETCH_SIZE (the same number when all requests
+        # are 128-byte ones, which is what this kernel produces).  WRITE_SIZE is exact.
         import csv
 
         try:
             with open(args.pmc_csv, newline="") as fh:
                 counters = {row["counter"]: float(row["mean_per_launch"]) for row in csv.DictReader(l for l in fh if not l.startswith("#"))}
-            fetch, write = counters["FETCH_SIZE"] * 1024, counters["WRITE_SIZE"] * 1024
+            fetch_raw, write = counters["FETCH_SIZE"] * 1024, counters["WRITE_SIZE"] * 1024
+            if all(k in counters for k in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_128B_sum")):
+                n, n32, n128 = counters["TCC_EA0_RDREQ_sum"], counters["TCC_EA0_RDREQ_32B_sum"], counters["TCC_EA0_RDREQ_128B_sum"]
+                fetch, how = 128.0 * n128 + 64.0 * max(0.0, n - n32 - n128) + 32.0 * n32, "request counters by size (TCC_EA0_RDREQ_32B / _128B / total)"
+            else:
+                fetch, how = 2.0 * fetch_raw, "2 x FETCH_SIZE (every read request of this kernel is a 128-byte line tallied at 64 bytes)"
             launches = max(1, k_draws)
             pixel_bytes = 4 * sum(pixels[s] for s in steps) / launches
             result["roofline"]["traffic"] = int(fetch + write)
             result["roofline"]["traffic_detail"] = {
-                "fetch_bytes_raw": int(fetch), "fetch_bytes_x2": int(2 * fetch), "write_bytes": int(write),
+                "fetch_bytes": int(fetch), "fetch_calibration": how, "fetch_size_counter_raw": int(fetch_raw), "write_bytes": int(write),
                 "algorithmic_pixel_bytes": int(pixel_bytes), "write_amplification": round(write / max(1.0, pixel_bytes), 3),
+                "fabric_TB_per_s": round((fetch + write) / (k_ms_total / max(1, k_draws)) / 1e9, 3),
                 "tcc_hit_rate": (round(counters["TCC_HIT_sum"] / max(1.0, counters["TCC_HIT_sum"] + counters["TCC_MISS_sum"]), 4)
                                  if "TCC_HIT_sum" in counters and "TCC_MISS_sum" in counters else None),
-                "source": f"{os.path.relpath(args.pmc_csv, ROOT)}: rocprofv3 --pmc passes of this workload with this build (stamped with the sha-256 of the kernel sources), per launch of render_kernel<false>",
+                "source": f"{os.path.relpath(args.pmc_csv, ROOT)}: rocprofv3 --pmc passes of this workload with this library (stamped with its sha-256 and the bench arguments), per launch of render_kernel<false>",
             }
         except (OSError, KeyError, ValueError) as e:
             result["roofline"]["traffic_detail"] = {"error": f"unreadable counter summary {args.pmc_csv}: {e}"}
@@ -615,11 +623,13 @@ def find_counter_summary(args):
     build or of another shape are never attached to the line (roofline.traffic stays null)."""
     import glob
 
+    if os.environ.get("CVX_GPU_LIB"):
+        return None  # another build of the ABI was selected: no committed counters belong to it
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     try:
-        from pmc_aggregate import kernel_sources_sha256
+        from pmc_aggregate import kernel_sources_sha256, library_sha256
 
-        mine = kernel_sources_sha256()
+        mine, mine_lib = kernel_sources_sha256(), library_sha256(gpu.lib_path())
     except Exception:  # noqa: BLE001
         return None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_render_kernel.csv")), reverse=True):
@@ -630,12 +640,13 @@ def find_counter_summary(args):
                 continue
             stamp = json.loads(first[1:])
             ap = argparse.ArgumentParser()
-            for flag, typ in (("--frames", int), ("--width", int), ("--height", int), ("--world", str), ("--lod-error", float), ("--pose-range", str)):
+            for flag, typ in (("--frames", int), ("--width", int), ("--height", int), ("--world", str), ("--lod-error", float), ("--pose-range", str), ("--steps", int), ("--warmup", int)):
                 ap.add_argument(flag, type=typ, default=None)
             theirs, _ = ap.parse_known_args(stamp.get("bench_args", []))
             same = all((getattr(theirs, k) if getattr(theirs, k) is not None else parse_default(k)) == getattr(args, k)
-                       for k in ("frames", "width", "height", "world", "lod_error", "pose_range"))
-            if stamp.get("kernel_sources_sha256") == mine and same:
+                       for k in ("frames", "width", "height", "world", "lod_error", "pose_range", "steps", "warmup"))
+            # the library ITSELF must be the one the counters were collected with (the build is deterministic), not just its sources
+            if stamp.get("kernel_sources_sha256") == mine and stamp.get("library_sha256") == mine_lib and same:
                 return path
         except (OSError, ValueError):
             continue
@@ -643,7 +654,7 @@ def find_counter_summary(args):
 
 
 def parse_default(name):
-    return {"frames": 512, "width": 1920, "height": 1080, "world": "proc2048", "lod_error": 1.0, "pose_range": None}[name]
+    return {"frames": 512, "width": 1920, "height": 1080, "world": "proc2048", "lod_error": 1.0, "pose_range": None, "steps": 10, "warmup": 2}[name]
 
 
 def cpu_baseline(ws, frames, W, H, budget_s: float, parity_frames=()):

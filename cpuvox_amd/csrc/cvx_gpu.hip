@@ -773,13 +773,17 @@ int DrawBatch(cvx_context *ctx, int frameCount, const cvx_segment_data *segments
 		// fitted to the sweeps in profiles/r02_occupancy.md: a wave of 64 / 32 / 16 / 8 ... lanes costs 1 / 0.68 / 0.40 / 0.25 ... of
 		// a full one, and throughput grows with (resident waves)^0.4 (at most 16 per CU: 128 VGPRs).  1080p picks 10 KB (every
 		// top / bottom tile stays whole), 4K picks 17 KB (68-word top / bottom tiles whole, left / right tiles halved).
-		// Round 4: the choice is made PER TILE and the waves are grouped into LDS classes, each class its own launch on its own stream (Launch).  Before, a
-		// launch had one LDS size -- the largest wave's -- so at 4K a 68-word top / bottom tile put 17 KB on every wave of the draw (9 resident waves per
-		// CU) although half the tiles of a frame with its vanishing point on the screen need 34 words or fewer.  Same cost model as before (a wave of
-		// 64 / 32 / 16 / 8 ... lanes costs 1 / 0.68 / 0.40 / 0.25 ... of a full one; throughput grows with (resident waves)^0.4, at most 16 per CU), applied
-		// to the tile alone: cut it into 2^k waves where k minimises (waves x lane cost) / (waves of that size a CU holds)^0.4.
+		// Round 4 built LDS classes: the waves of a draw grouped by the mask their window needs (<= 10 KB, <= 17 KB, more), every class a
+		// launch of its own with its own dynamic-LDS size on its own stream, so that a 68-word 4K tile would no longer put 17 KB on every wave of the draw.  The
+		// launches do run side by side (rocprofv3 kernel trace: both start within 7 us), and the draw is SLOWER: 4K / 2048^3 25.0 against 23.2 ms per 128 frames,
+		// 4K / 4096^3 11.4 against 10.6, 1080p with a class for the 41..60-word left / right tiles 16.7 against 13.2 (profiles/r04_experiments.md).  The kernel
+		// is bound by vector issue now (profiles/r04_issue_model.md), so 16 instead of 9 resident waves per CU buy nothing, while every class starts its
+		// longest tiles at once and the longest-first order across the draw is lost.  Kept behind -DCVX_EXP_LDS_CLASSES; the product makes ONE launch.
+		// Likewise measured: choosing the split per tile instead of by one budget per draw (-DCVX_EXP_PER_TILE_RULE), 3.6 % slower at 1080p.
 		static const double laneCost[7] = { 1.0, 0.68, 0.40, 0.25, 0.16, 0.11, 0.08 }; // 64, 32, 16, 8, 4, 2, 1 lanes
+#ifdef CVX_EXP_LDS_CLASSES
 		static const int classLimit[cvx_context::kLaunchClasses] = { 40 * CVX_WAVE, 68 * CVX_WAVE, 1 << 30 }; // 10 KB (16 waves per CU), 17 KB (9), the rest
+#endif
 		auto residentWaves = [](int waveWords) { return std::max(1, std::min(16, (int)(163840 / ((size_t)waveWords * 4)))); };
 		int baseLevel = 0;
 		while ((1 << baseLevel) < split) { baseLevel++; }
@@ -832,7 +836,7 @@ int DrawBatch(cvx_context *ctx, int frameCount, const cvx_segment_data *segments
 			}
 			const int lanesPerWave = CVX_WAVE / tileSplit;
 			int cls = 0;
-#ifndef CVX_EXP_ONE_LDS_CLASS
+#ifdef CVX_EXP_LDS_CLASSES /* measured and lost (see above): one launch per LDS class */
 			while (cls + 1 < cvx_context::kLaunchClasses && words * lanesPerWave > classLimit[cls]) { cls++; }
 #endif
 			classWords[cls] = std::max(classWords[cls], words * lanesPerWave);

@@ -1016,7 +1016,15 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		return m_min(ex, ez);
 	};
 	bool nearEdge = false; // beyond edgeDistance(): every column comes up for the exact test
-	float stopDist = m_min(m_min(farClip, lodMax), edgeDistance());
+	// ... and a checkpoint: the three crossings of slack cover the rounding of the DDA's own additions (tMax += tDelta, n of them drift by <= n^2 2^-24
+	// tDelta) only for a few thousand crossings, and the library accepts worlds of up to 32768 columns a side with LOD distances of the caller's choice.
+	// So the untested stretch is at most 1024 crossings of the faster axis long (drift <= 0.07 crossings); a ray that reaches the checkpoint comes up
+	// below the loop, takes a fresh edge distance from where it stands and goes on -- once per ~1000 columns.
+	auto stopDistance = [&]() -> float {
+		const float checkpoint = ray.distLast + 1024.0f * hw_min(ray.tDeltaX, ray.tDeltaZ);
+		return m_min(m_min(m_min(farClip, lodMax), edgeDistance()), checkpoint);
+	};
+	float stopDist = stopDistance();
 	// one column step: `header` / `queue` = the column to process (already fetched), `nextHeader` / `nextQueue` receive the look-ahead
 	auto columnStep = [&](const uint4 &header, const uint4 &queue, uint4 &nextHeader, uint4 &nextQueue, auto guardTag) {
 		constexpr bool GUARD = decltype(guardTag)::value;
@@ -1102,10 +1110,12 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			break; // finished: window closed / frustum left the world / step guard, far clip (:273), left the world (:613)
 		}
 		if (!(ray.distLast >= lodMax)) {
-			// neither: the ray is within a few columns of the world's edge.  From here on it comes up after every column (stopDist below every
-			// distance); the record of the column it stands on was fetched into the other register pair: fetched again (a handful of times per ray)
-			nearEdge = true;
-			stopDist = -__builtin_inff();
+			// neither: a checkpoint, or the ray is within a few columns of the world's edge.  A fresh stop distance beyond where the ray stands means the
+			// edge is still more than three crossings away: on with the loop.  Else it comes up after every column from here on (stopDist below every
+			// distance).  Either way the record of the column it stands on was fetched into the other register pair: fetched again (a handful of times per ray)
+			const float fresh = nearEdge ? -__builtin_inff() : stopDistance();
+			nearEdge = !(fresh > ray.distLast);
+			stopDist = nearEdge ? -__builtin_inff() : fresh;
 			header = ld4(arena, cur.rec);
 			queue = ld4(arena, cur.rec + 16u);
 			go = true;
@@ -1122,7 +1132,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		L = world->level[lod];
 		{ const float next_ = F.lod[min(lod, 5)]; lodMax = lod < 5 ? next_ : __builtin_inff(); }
 		cursor_set(cur, ray, L, maskX, maskZ);
-		stopDist = nearEdge ? -__builtin_inff() : m_min(m_min(farClip, lodMax), edgeDistance());
+		stopDist = nearEdge ? -__builtin_inff() : stopDistance();
 		header = ld4(arena, cur.rec);
 		queue = ld4(arena, cur.rec + 16u);
 		go = true;

@@ -48,6 +48,20 @@ def load_world(name: str) -> host.WorldSet:
         else:
             dx = dy = dz = int(spec)
         ws = host.WorldSet.procedural(dx, dy, dz, seed)
+    elif name.startswith("stripes"):
+        # run-rich world for the slow paths of the element walk: every column is a stack of 8..30 solid bands (thickness 1..5, period 6..20, phase and
+        # colours hashed from the position), 'stripes<X>x<Y>x<Z>'.  Most columns have far more than the two runs a device record holds.
+        dx, dy, dz = (int(v) for v in name[7:].split("x"))
+        x, y, z = np.meshgrid(np.arange(dx, dtype=np.int64), np.arange(dy, dtype=np.int64), np.arange(dz, dtype=np.int64), indexing="ij")
+        h = (x * 73856093) ^ (z * 19349663)
+        period = 6 + (h >> 3) % 15
+        thick = 1 + (h >> 9) % 5
+        phase = (h >> 14) % period
+        solid = ((y + phase) % period) < np.minimum(thick, period - 1)
+        solid &= ~(((x + 2 * z) % 11 == 0) & (y > dy // 2))  # some columns lose their upper half: uneven run counts between neighbours
+        xs, ys, zs = x[solid], y[solid], z[solid]
+        argb = (0xFF000000 | (((xs * 2654435761 + ys * 40503 + zs * 2246822519) >> 7) & 0xFFFFFF)).astype(np.uint32)
+        ws = host.WorldSet.from_voxels((dx, dy, dz), xs, ys, zs, argb)
     else:
         raise KeyError(name)
     _world_cache[name] = ws

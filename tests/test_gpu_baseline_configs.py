@@ -93,6 +93,30 @@ def test_config3_single_draws(proc2048):
     assert (seen_lods[:3] > 0).all() and (seen_lods[3:] == 0).all(), seen_lods
 
 
+def test_config3_bench_launch_512_frames():
+    """exactly the launch bench.py times -- 512 frames of the benchmark path (pose (g * 37) % 1000 for frame g) in ONE draw of
+    the shipped build at 1080p, the LDS budget / sub-tile decisions DrawBatch makes for THAT batch -- with 40 frames spread over the launch
+    (every 13th: first, last, all four segment shapes of the path) compared with the oracle, every pixel they write."""
+    ws = scenes.load_world("proc2048")
+    W, H, F = 1920, 1080, 512
+    ctx = gpu.Context(0, buffer_count=F)
+    try:
+        ctx.upload_world(ws)
+        ctx.set_resolution(W, H)
+        lods, far = _lods(ws, W, H, 1.0)
+        frames = [_path_frame(ws, W, H, (g * 37) % POSES, lods, far) for g in range(F)]
+        checked = list(range(0, F, 13)) + [F - 1]
+        for b in checked:
+            ctx.clear_raybuffers(b, CLEAR)
+        ctx.enable_counters(False)
+        ctx.draw_segments_batch(frames, 0)
+        for b in checked:
+            o_td, o_lr, _ = O.draw_segments(ws, frames[b], W, H, clear=CLEAR, counters=False)
+            _compare(f"bench launch frame {b} (pose {(b * 37) % POSES})", frames[b], ctx.read_raybuffer(b, 0), ctx.read_raybuffer(b, 1), o_td, o_lr)
+    finally:
+        ctx.close()
+
+
 def test_config3_one_64_frame_batch(proc2048):
     """The shape bench.py times: 64 frames in ONE launch (no sub-tile split at this size), every frame against the oracle."""
     ws, ctx = proc2048

@@ -8,7 +8,7 @@ import pytest
 
 import oraclelib as O
 import scenes
-from cpuvox_amd import gpu
+from cpuvox_amd import gpu, host
 
 pytestmark = pytest.mark.gpu
 
@@ -426,6 +426,64 @@ def test_short_division_is_ieee_division(diag_context):
         # div_safe: magnitude in [2^-30, 2^30]
         mag = np.abs(a)
         assert np.array_equal(ctx.selftest_math(15, a, b) == 1.0, (mag >= np.float32(2.0 ** -30)) & (mag <= np.float32(2.0 ** 30)))
+
+
+def test_run_rich_world_slow_paths(contexts):
+    """the paths the ordinary scenes rarely take, forced.  World `stripes128x256x128`: every column a stack of 8 .. 30 solid
+    bands (~30 RLE elements per column against ~3 in the terrain worlds), so nearly every drawn column has runs beyond the two a device record
+    holds (the run-list scan, `ovPending`, top-down AND bottom-up) and many runs are drawn per column.  Cameras above the world looking down and
+    below it looking up: the world's columns then project INSIDE the pixel window instead of straddling it, so every frustum clip takes the
+    reference's own path (`windowUntouched == false`: the four projections, floor / ceil, the window update and the window-closed exit) instead
+    of the proven shortcut; cameras inside the world for the straddling case next to it.  Both iteration directions, counting and rendering
+    build, two resolutions, against the oracle."""
+    name = "stripes128x256x128"
+    ws = scenes.load_world(name)
+    poses = [((64.3, 128.0, 20.2), (0.0, 10.0, 0.0)), ((64.3, 400.0, 64.2), (60.0, 30.0, 0.0)), ((20.3, 420.0, 30.2), (35.0, 45.0, 0.0)),
+             ((64.3, 520.0, 64.2), (86.0, 120.0, 0.0)), ((64.3, -120.0, 64.2), (-55.0, 200.0, 0.0)), ((100.3, -200.0, 90.2), (-30.0, 300.0, 0.0)),
+             ((64.3, 100.0, 64.2), (25.0, 77.0, 0.0)), ((5.3, 200.0, 120.2), (-20.0, 135.0, 0.0)), ((64.3, 300.0, 64.2), (89.0, 0.0, 33.0))]
+    directions = set()
+    for W, H in ((320, 200), (517, 333)):
+        ctx = contexts(name, W, H)
+        for pos, eul in poses:
+            fr = scenes.make_frame(ws, W, H, pos, eul)
+            directions.add(bool(fr.camera.InverseElementIterationDirection))
+            o_td, o_lr, cnt = O.draw_segments(ws, fr, W, H, clear=CLEAR)
+            assert cnt.E > 15 * cnt.S, "the world is not run-rich for this pose"
+            for counting in (True, False):
+                g_td, g_lr = _render_gpu(ctx, fr, counters=counting)
+                _compare(f"stripes {W}x{H} pos={pos} eul={eul} counting={counting}", fr, g_td, g_lr, o_td, o_lr)
+                if counting:
+                    gc = ctx.counters()
+                    assert (gc.S, gc.E, gc.C, gc.P, gc.R) == (cnt.S, cnt.E, cnt.C, cnt.P, cnt.R), (gc.as_dict(), cnt.as_dict())
+    assert directions == {False, True}, "both element iteration directions must be covered"
+
+
+def test_long_world_far_edge_checkpoints(contexts):
+    """a ray that makes more than ~9 000 crossings on one axis at one LOD level.  The column loop tests the ray's position
+    only beyond a stop distance `tMax + (n - 4) tDelta`; the DDA's own additions drift by ~n^2 2^-24 tDelta, so over 16 384 crossings the three
+    crossings of slack would be used up five times over.  The kernel therefore renews the stop distance every 1024 crossings.  World: 16384 x 1024
+    x 256 columns, LOD distances and far clip beyond the world (the caller's choice at the boundary: CameraData.LODDistances / FarClip), cameras
+    above the terrain looking along x: about a dozen rays per frame walk the whole length and leave through the far edge, the others through the
+    sides.  Rendering AND counting build against the oracle (pixels; S / P of the counting build)."""
+    name = "proc16384x1024x256"
+    ws = scenes.load_world(name)
+    W, H = 1280, 160
+    ctx = contexts(name, W, H)
+    poses = [((3.5, 900.0, 128.5), (0.0, 90.0, 0.0)), ((16380.5, 880.0, 100.2), (0.2, 270.01, 0.0)), ((-3000.0, 870.0, 127.3), (-0.1, 90.0, 0.0)),
+             ((8000.0, 860.0, 30.3), (0.1, 89.2, 0.0)), ((100.5, 850.0, 250.0), (0.0, 91.0, 0.0))]
+    longest = 0
+    for pos, eul in poses:
+        pose = host.camera_pose(pos, eul, W, H)
+        fr = host.setup_frame(pose, [200000.0] * 6, 100000.0, W, H, ws.dims[1], True)
+        o_td, o_lr, cnt = O.draw_segments(ws, fr, W, H, clear=CLEAR)
+        for counting in (True, False):
+            g_td, g_lr = _render_gpu(ctx, fr, counters=counting)
+            _compare(f"long world pos={pos} eul={eul} counting={counting}", fr, g_td, g_lr, o_td, o_lr)
+            if counting:
+                gc = ctx.counters()
+                assert (gc.S, gc.E, gc.C, gc.P, gc.R) == (cnt.S, cnt.E, cnt.C, cnt.P, cnt.R), (gc.as_dict(), cnt.as_dict())
+        longest = max(longest, cnt.S)
+    assert longest > 10 * 16000, "no frame with ~a dozen rays along the whole world: the scenario no longer exercises the checkpoints"
 
 
 def test_errors_are_reported_not_swallowed():

@@ -28,6 +28,13 @@ def kernel_sources_sha256() -> str:
     return h.hexdigest()
 
 
+def library_sha256(path=None) -> str:
+    """Identity of the library the counters were collected with: the file itself (the build is deterministic: same sources and flags, same bytes)."""
+    path = path or os.path.join(ROOT, "cpuvox_amd", "libcpuvox_gpu.so")
+    with open(path, "rb") as fh:
+        return hashlib.sha256(fh.read()).hexdigest()
+
+
 def main():
     outdir, needle = sys.argv[1], sys.argv[2]
     per_dispatch = defaultdict(float)
@@ -41,7 +48,7 @@ def main():
     for (_, _, name), v in per_dispatch.items():
         sums[name] += v
         counts[name] += 1
-    stamp = {"kernel_sources_sha256": kernel_sources_sha256(), "bench_args": sys.argv[3:]}
+    stamp = {"kernel_sources_sha256": kernel_sources_sha256(), "library_sha256": library_sha256(), "bench_args": sys.argv[3:]}
     print("# " + json.dumps(stamp))
     print("counter,mean_per_launch,launches")
     for name in sums:

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything profiles/rNN_* is made from, in one go on the GPU box: tools/profile_round.sh <tag, e.g. r02>
 # (kernel trace + stats, PMC passes, SQ stall / instruction counters of the default bench command; results under gpurun_out/<tag>/)
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -10,8 +10,9 @@ cd /tmp; export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$R/bench.py" --cpu-seconds 0 --latency-frames 0 > "$OUT/trace_bench.json" 2> "$OUT/trace.log"
 find "$OUT/trace" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
 # 2. counter passes (separate runs, --pmc only)
-bash "$R/tools/pmc_passes.sh" "$OUT/pmc" --cpu-seconds 0 --latency-frames 0 --steps 3 --warmup 1 > "$OUT/pmc_passes.log" 2>&1
-python3 "$R/tools/pmc_aggregate.py" "$OUT/pmc" "render_kernel<false>" --cpu-seconds 0 --latency-frames 0 --steps 3 --warmup 1 > "$OUT/pmc_render_kernel.csv"
+# (the default --steps / --warmup: the same frames as the bench line the summary is attached to)
+bash "$R/tools/pmc_passes.sh" "$OUT/pmc" --cpu-seconds 0 --latency-frames 0 > "$OUT/pmc_passes.log" 2>&1
+python3 "$R/tools/pmc_aggregate.py" "$OUT/pmc" "render_kernel<false>" --cpu-seconds 0 --latency-frames 0 > "$OUT/pmc_render_kernel.csv"
 # 3. the bench line of this build with the measured traffic attached (and the CPU leg, parity check, latency legs)
 timeout 900 python3 "$R/bench.py" --pmc-csv "$OUT/pmc_render_kernel.csv" > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
 # 4. SQ counters (128 frames per launch)

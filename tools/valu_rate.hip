@@ -102,6 +102,31 @@ struct WaveRec {
 	                      "s_and_b64 s[20:21], exec, s[22:23]\n v_cndmask_b32_e64 %2, %8, %9, s[20:21]\n s_or_b64 s[24:25], exec, s[22:23]\n v_cndmask_b32_e64 %3, %8, %9, s[24:25]\n" \
 	                      "s_and_b64 s[20:21], exec, s[22:23]\n v_cndmask_b32_e64 %4, %8, %9, s[20:21]\n s_or_b64 s[24:25], exec, s[22:23]\n v_cndmask_b32_e64 %5, %8, %9, s[24:25]\n" \
 	                      "s_and_b64 s[20:21], exec, s[22:23]\n v_cndmask_b32_e64 %6, %8, %9, s[20:21]\n s_or_b64 s[24:25], exec, s[22:23]\n v_cndmask_b32_e64 %7, %8, %9, s[24:25]\n") \
+	/* round 4, second question: is a compare / select through VCC (VOP2 / VOPC encoding) cheaper than the VOP3 form with an SGPR pair when other    \
+	   work sits between them?  Four instructions per group, one compare or select in each */                                                       \
+	X(mix_cmp_e64, "", T2("v_cmp_lt_f32 s[20:21], %8, %0\n v_add_f32 %1, %8, %1\n v_add_f32 %2, %8, %2\n v_add_f32 %3, %8, %3\n"                    \
+	                      "v_cmp_lt_f32 s[22:23], %8, %4\n v_add_f32 %5, %8, %5\n v_add_f32 %6, %8, %6\n v_add_f32 %7, %8, %7\n"))                   \
+	X(mix_cmp_e32, "", T2("v_cmp_lt_f32 vcc, %8, %0\n v_add_f32 %1, %8, %1\n v_add_f32 %2, %8, %2\n v_add_f32 %3, %8, %3\n"                         \
+	                      "v_cmp_lt_f32 vcc, %8, %4\n v_add_f32 %5, %8, %5\n v_add_f32 %6, %8, %6\n v_add_f32 %7, %8, %7\n"))                        \
+	X(mix_cmp_e32_smov, "", "v_cmp_lt_f32 vcc, %8, %0\n s_mov_b64 s[20:21], vcc\n v_add_f32 %1, %8, %1\n v_add_f32 %2, %8, %2\n v_add_f32 %3, %8, %3\n" \
+	                        "v_cmp_lt_f32 vcc, %8, %4\n s_mov_b64 s[22:23], vcc\n v_add_f32 %5, %8, %5\n v_add_f32 %6, %8, %6\n v_add_f32 %7, %8, %7\n" \
+	                        "v_cmp_lt_f32 vcc, %8, %0\n s_mov_b64 s[24:25], vcc\n v_add_f32 %1, %8, %1\n v_add_f32 %2, %8, %2\n v_add_f32 %3, %8, %3\n" \
+	                        "v_cmp_lt_f32 vcc, %8, %4\n v_add_f32 %5, %8, %5\n v_add_f32 %6, %8, %6\n v_add_f32 %7, %8, %7\n")                       \
+	X(mix_cnd_e64, "", T2("v_cndmask_b32_e64 %0, %8, %9, s[22:23]\n v_add_f32 %1, %8, %1\n v_add_f32 %2, %8, %2\n v_add_f32 %3, %8, %3\n"           \
+	                      "v_cndmask_b32_e64 %4, %8, %9, s[24:25]\n v_add_f32 %5, %8, %5\n v_add_f32 %6, %8, %6\n v_add_f32 %7, %8, %7\n"))          \
+	X(mix_cnd_e32_smov, "", "s_mov_b64 vcc, s[22:23]\n v_cndmask_b32 %0, %8, %9, vcc\n v_add_f32 %1, %8, %1\n v_add_f32 %2, %8, %2\n v_add_f32 %3, %8, %3\n" \
+	                        "s_mov_b64 vcc, s[24:25]\n v_cndmask_b32 %4, %8, %9, vcc\n v_add_f32 %5, %8, %5\n v_add_f32 %6, %8, %6\n v_add_f32 %7, %8, %7\n" \
+	                        "s_mov_b64 vcc, s[22:23]\n v_cndmask_b32 %0, %8, %9, vcc\n v_add_f32 %1, %8, %1\n v_add_f32 %2, %8, %2\n v_add_f32 %3, %8, %3\n" \
+	                        "v_cndmask_b32 %4, %8, %9, vcc\n v_add_f32 %5, %8, %5\n v_add_f32 %6, %8, %6\n v_add_f32 %7, %8, %7\n")                  \
+	X(mix_min, "", T2("v_min_f32 %0, %8, %0\n v_add_f32 %1, %8, %1\n v_add_f32 %2, %8, %2\n v_add_f32 %3, %8, %3\n"                               \
+	                  "v_min_f32 %4, %8, %4\n v_add_f32 %5, %8, %5\n v_add_f32 %6, %8, %6\n v_add_f32 %7, %8, %7\n"))                                \
+	X(mix_lshl, "", T2("v_lshlrev_b32 %0, 1, %0\n v_add_f32 %1, %8, %1\n v_add_f32 %2, %8, %2\n v_add_f32 %3, %8, %3\n"                            \
+	                   "v_lshlrev_b32 %4, 1, %4\n v_add_f32 %5, %8, %5\n v_add_f32 %6, %8, %6\n v_add_f32 %7, %8, %7\n"))                            \
+	X(mix_cmp_cnd_e64, "", T2("v_cmp_lt_f32 s[20:21], %8, %0\n v_add_f32 %1, %8, %1\n v_cndmask_b32_e64 %2, %8, %9, s[20:21]\n v_add_f32 %3, %8, %3\n" \
+	                          "v_cmp_lt_f32 s[22:23], %8, %4\n v_add_f32 %5, %8, %5\n v_cndmask_b32_e64 %6, %8, %9, s[22:23]\n v_add_f32 %7, %8, %7\n")) \
+	X(mix_cmp_cnd_e32, "", T2("v_cmp_lt_f32 vcc, %8, %0\n v_add_f32 %1, %8, %1\n v_cndmask_b32 %2, %8, %9, vcc\n v_add_f32 %3, %8, %3\n"           \
+	                          "v_cmp_lt_f32 vcc, %8, %4\n v_add_f32 %5, %8, %5\n v_cndmask_b32 %6, %8, %9, vcc\n v_add_f32 %7, %8, %7\n"))         \
+	X(mix_add_only, "", T2(D8("v_add_f32 ", ", %8, ")))                                                                            \
 	/* scalar side */                                                                                                           \
 	X(salu_and, "", "s_and_b64 s[20:21], s[20:21], s[22:23]\n s_or_b64 s[22:23], s[22:23], s[24:25]\n s_and_b64 s[24:25], s[24:25], s[26:27]\n s_or_b64 s[26:27], s[26:27], s[20:21]\n" \
 	                "s_and_b64 s[20:21], s[20:21], s[22:23]\n s_or_b64 s[22:23], s[22:23], s[24:25]\n s_and_b64 s[24:25], s[24:25], s[26:27]\n s_or_b64 s[26:27], s[26:27], s[20:21]\n" \
