@@ -632,7 +632,7 @@ def find_counter_summary(args):
         mine, mine_lib = kernel_sources_sha256(), library_sha256(gpu.lib_path())
     except Exception:  # noqa: BLE001
         return None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_render_kernel.csv")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_render_kernel*.csv")), reverse=True):
         try:
             with open(path) as fh:
                 first = fh.readline()

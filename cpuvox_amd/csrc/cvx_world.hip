@@ -242,7 +242,11 @@ int DownsampleDevice(cvx_context *ctx, const uint8_t *dSrc, int dimX, int dimY, 
 		}                                                                                                                 \
 	} while (0)
 	const size_t headerWords = (size_t)allocatedColumns * 3;
-	CVX_DS(hipMalloc((void **)&dAlloc, (size_t)targetColumns * 2 * sizeof(uint32_t)));
+	// (+ the chunk sums of the offset scan behind the two tables, 8-byte aligned)
+	const size_t scanChunks = (size_t)((targetColumns + CVX_SCAN_CHUNK - 1) / CVX_SCAN_CHUNK);
+	const size_t tableWords = ((size_t)targetColumns * 2 + 1) & ~(size_t)1;
+	CVX_DS(hipMalloc((void **)&dAlloc, tableWords * sizeof(uint32_t) + (scanChunks + 1) * sizeof(unsigned long long)));
+	unsigned long long *dChunkSums = reinterpret_cast<unsigned long long *>(dAlloc + tableWords);
 	CVX_DS(hipMalloc((void **)&dHeaders, headerWords * sizeof(uint32_t)));
 	CVX_DS(hipMalloc((void **)&dScalars, 3 * sizeof(unsigned long long)));
 	CVX_DS(hipEventCreate(&evBegin));
@@ -280,7 +284,12 @@ int DownsampleDevice(cvx_context *ctx, const uint8_t *dSrc, int dimX, int dimY, 
 	} else {
 		hipLaunchKernelGGL((cvxk::downsample_kernel<false>), dim3((unsigned)targetColumns), dim3(dsThreads), dsLdsBytes, ctx->stream, P, O);
 	}
-	hipLaunchKernelGGL(cvxk::exclusive_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, dAlloc, (int)targetColumns, dScalars + 1);
+	{ // exclusive scan of the element counts: chunk sums, their offsets, the chunks again (cvx_downsample.h)
+		const unsigned chunks = (unsigned)((targetColumns + CVX_SCAN_CHUNK - 1) / CVX_SCAN_CHUNK);
+		hipLaunchKernelGGL(cvxk::scan_chunk_sums_kernel, dim3(chunks), dim3(CVX_SCAN_THREADS), 0, ctx->stream, dAlloc, (int)targetColumns, dChunkSums);
+		hipLaunchKernelGGL(cvxk::scan_chunk_offsets_kernel, dim3(1), dim3(CVX_SCAN_THREADS), 0, ctx->stream, dChunkSums, (int)chunks, dScalars + 1);
+		hipLaunchKernelGGL(cvxk::scan_apply_kernel, dim3(chunks), dim3(CVX_SCAN_THREADS), 0, ctx->stream, dAlloc, (int)targetColumns, dChunkSums);
+	}
 	CVX_DS(hipGetLastError());
 	unsigned long long scalars[3] = { 0, 0, 0 };
 	CVX_DS(hipMemcpyAsync(scalars, dScalars, sizeof scalars, hipMemcpyDeviceToHost, ctx->stream));

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collects rocprofv3 PMC counters for bench.py in small passes (one hardware block / few slots per pass; a pass that asks
 # for more than the hardware can collect aborts and hangs, so every pass runs under its own timeout).
-# usage: tools/pmc_passes.sh <outdir> [bench args...]
+# usage: [PMC_ONLY_TRAFFIC=1] tools/pmc_passes.sh <outdir> [bench args...]     (PMC_ONLY_TRAFFIC: just the passes roofline.traffic needs)
 set -u
 OUT=$1; shift
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -10,8 +10,9 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 while read -r counters; do
   [ -z "$counters" ] && continue
+  if [ -n "${PMC_ONLY_TRAFFIC:-}" ]; then case "$counters" in FETCH_SIZE*|WRITE_SIZE*|TCC_EA0_*) ;; *) continue ;; esac; fi
   i=$((i+1))
-  timeout 150 rocprofv3 --pmc $counters --output-format csv -d "$OUT/pass$i" -- python3 "$R/bench.py" "$@" > "$OUT/pass$i.log" 2>&1
+  timeout ${PMC_PASS_TIMEOUT:-240} rocprofv3 --pmc $counters --output-format csv -d "$OUT/pass$i" -- python3 "$R/bench.py" "$@" > "$OUT/pass$i.log" 2>&1
   echo "pass$i ($counters) rc=$?"
 done <<'LIST'
 TA_TA_BUSY_sum GRBM_GUI_ACTIVE

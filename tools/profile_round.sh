@@ -18,10 +18,16 @@ timeout 900 python3 "$R/bench.py" --pmc-csv "$OUT/pmc_render_kernel.csv" > "$OUT
 # 4. SQ counters (128 frames per launch)
 bash "$R/tools/pmc_stalls.sh" libcpuvox_gpu.so > "$OUT/sq_counters.txt" 2>&1
 bash "$R/tools/pmc_insts.sh" libcpuvox_gpu.so >> "$OUT/sq_counters.txt" 2>&1
-# 5. other shapes
-timeout 600 python3 "$R/bench.py" --cpu-seconds 0 --latency-frames 0 --frames 128 --steps 4 --warmup 1 --width 3840 --height 2160 > "$OUT/bench_config4_1gpu.json" 2>/dev/null
-timeout 900 python3 "$R/bench.py" --cpu-seconds 0 --latency-frames 0 --frames 64 --steps 4 --warmup 1 --width 3840 --height 2160 --world proc4096 --lod-error 4 > "$OUT/bench_config5_1gpu.json" 2>/dev/null
-rm -rf "$OUT/trace" "$OUT/pmc"/pass*/runc "$OUT"/pmc/pass*/*/*agent_info.csv 2>/dev/null
+# 5. the 4K configurations (BASELINE.json configs 4 and 5 on one GPU): their own stamped traffic counters, then the bench line WITH the CPU leg (parity_checked)
+C4="--frames 128 --steps 4 --warmup 1 --width 3840 --height 2160"
+C5="--frames 64 --steps 4 --warmup 1 --width 3840 --height 2160 --world proc4096 --lod-error 4"
+PMC_ONLY_TRAFFIC=1 bash "$R/tools/pmc_passes.sh" "$OUT/pmc4" --cpu-seconds 0 --latency-frames 0 $C4 > "$OUT/pmc4_passes.log" 2>&1
+python3 "$R/tools/pmc_aggregate.py" "$OUT/pmc4" "render_kernel<false>" --cpu-seconds 0 --latency-frames 0 $C4 > "$OUT/pmc_render_kernel_config4.csv"
+timeout 900 python3 "$R/bench.py" --cpu-seconds 15 --latency-frames 0 $C4 --pmc-csv "$OUT/pmc_render_kernel_config4.csv" > "$OUT/bench_config4_1gpu.json" 2> "$OUT/bench_config4.err"
+PMC_ONLY_TRAFFIC=1 PMC_PASS_TIMEOUT=400 bash "$R/tools/pmc_passes.sh" "$OUT/pmc5" --cpu-seconds 0 --latency-frames 0 $C5 > "$OUT/pmc5_passes.log" 2>&1
+python3 "$R/tools/pmc_aggregate.py" "$OUT/pmc5" "render_kernel<false>" --cpu-seconds 0 --latency-frames 0 $C5 > "$OUT/pmc_render_kernel_config5.csv"
+timeout 1100 python3 "$R/bench.py" --cpu-seconds 15 --latency-frames 0 $C5 --pmc-csv "$OUT/pmc_render_kernel_config5.csv" > "$OUT/bench_config5_1gpu.json" 2> "$OUT/bench_config5.err"
+rm -rf "$OUT/trace" "$OUT"/pmc*/pass*/runc "$OUT"/pmc*/pass*/*/*agent_info.csv 2>/dev/null
 ls -la "$OUT"
 cat "$OUT/kernel_stats.csv" | head -8
 cat "$OUT/pmc_render_kernel.csv"
