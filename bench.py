@@ -43,7 +43,11 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=512, help="frames per GPU per step (kept in flight in one launch)")
+    ap.add_argument("--frames", type=lambda v: v if v == "auto" else int(v), default=512,
+                    help="frames per GPU per step (kept in flight in one launch); 'auto': the largest of 512, 256, ... whose raybuffer areas (N > 1: send + display, two parities) fit --hbm-budget-gb")
+    ap.add_argument("--hbm-budget-gb", type=float, default=96.0, help="--frames auto: HBM this run may spend on raybuffer / exchange areas per GPU (a third of the 288 GB)")
+    ap.add_argument("--allow-fallback", action="store_true", help="N > 1: if frames assembled through cvx_exchange fail verification, re-time with the torch.distributed exchange (labelled) "
+                    "instead of printing the failure line and exiting with code 5")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--world", default="proc2048", help="proc<dim> | mill512 | mill256")
@@ -154,7 +158,7 @@ def main():
         if N > 1:
             dist.barrier()
 
-    W, H, F = args.width, args.height, args.frames
+    W, H = args.width, args.height
     ws = load_world(args.world, rank, N, barrier)
     dims = ws.dims
 
@@ -162,7 +166,6 @@ def main():
     pose0 = host.camera_pose((0, 0, 0), (0, 0, 0), W, H)
     lods, far = host.setup_lods(pose0, ws.max_dimension, W, H, args.lod_error)
     total_steps = args.warmup + args.steps
-    G = N * F  # frames per step, whole job
 
     def frame_for(g: int):
         i = (g * POSE_STRIDE) % POSES
@@ -172,6 +175,35 @@ def main():
         t = i / POSES * host.BENCHMARK_PATH_LENGTH
         pos, eul = host.sample_benchmark_path(t, dims)
         return host.setup_frame(host.camera_pose(pos, eul, W, H), lods, far, W, H, dims[1])
+
+    # ---- frames per GPU and step.  `auto`: the largest F whose areas fit the stated HBM budget -- one GPU: F raybuffer pairs;
+    # N > 1: per-destination send sections + the display area, two parities each (the shard plan of step 0 gives their exact sizes) -- and the
+    # payload every xGMI link would carry per step, printed before anything is allocated
+    predicted = None
+    if args.frames == "auto":
+        budget = args.hbm_budget_gb * 1e9
+        choice = None
+        for cand in (512, 256, 128, 64, 32, 16, 8):
+            if N > 1:
+                from cpuvox_amd import dist as cdist_
+
+                plan0 = cdist_.ShardPlan([frame_for(i) for i in range(N * cand)], W, H, rank, N)
+                area = 2.0 * (plan0.send_total + plan0.disp_total) * 256.0
+                per_link = plan0.send_total * 256.0 / max(1, N - 1)
+            else:
+                area = cand * 4.0 * (H * (W + 2 * H) + W * (2 * W + H))  # RenderManager.cs:35-36 capacities per raybuffer pair
+                per_link = 0.0
+            choice = (cand, area, per_link)
+            if area <= budget:
+                break
+        args.frames = choice[0]
+        predicted = {"frames_per_gpu": choice[0], "area_bytes_per_gpu": int(choice[1]), "hbm_budget_bytes": int(budget), "payload_bytes_per_link_per_step": int(choice[2]),
+                     "link_ms_at_153_GBps": round(choice[2] / 153e9 * 1e3, 3)}
+        if rank == 0:
+            print(f"bench.py: --frames auto -> {choice[0]} per GPU ({choice[1] / 1e9:.2f} GB of areas per GPU against a budget of {budget / 1e9:.0f} GB; "
+                  f"{choice[2] / 1e6:.1f} MB per peer and step = {choice[2] / 153e9 * 1e3:.2f} ms on one 153 GB/s xGMI link)", file=sys.stderr, flush=True)
+    F = args.frames
+    G = N * F  # frames per step, whole job
 
     steps_frames = [[frame_for(s * G + i) for i in range(G)] for s in range(total_steps)]
     rays_per_step = [sum(f.totalRays for f in frames) for frames in steps_frames]
@@ -391,6 +423,18 @@ def main():
     exchange_verified = None
     if sharded and not args.no_exchange:
         exchange_verified = verify_exchange(total_steps - 1)
+        if not exchange_verified and not args.allow_fallback:
+            # A run whose assembled frames are wrong has no number: rank 0 prints what was measured up to here as a FAILURE
+            # line -- no `value` -- and every rank exits non-zero.  (--allow-fallback re-times with the other exchange / without overlap instead.)
+            if rank == 0:
+                print(json.dumps({"metric": "Mrays/s, Phase-1 raybuffer rendering (DrawSegmentRayJob)", "value": None, "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+                                  "failure": "frames assembled from the ranks' tiles differ from the same frames rendered whole", "exchange_verified": False,
+                                  "exchange_path": exchange_path, "gather": args.gather, "overlap": overlap, "ranks_seen": ranks_seen,
+                                  "unverified_ms_per_step": round(elapsed / args.steps * 1e3, 4)}), flush=True)
+            ctx.close()
+            if N > 1:
+                dist.destroy_process_group()
+            raise SystemExit(5)
         if not exchange_verified and comm:
             # never report a number from a run whose frames are wrong: first fall back to the torch.distributed exchange
             gpu.comm_destroy(comm)
@@ -446,6 +490,7 @@ def main():
         "config": {
             "workload": workload,
             "frames_per_gpu_per_step": F,
+            "frames_auto": predicted,
             "frames_per_step": G,
             "rays_per_frame_mean": round(total_rays / total_frames, 1),
             "parallelism": parallelism,

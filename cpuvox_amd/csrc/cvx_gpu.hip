@@ -1221,7 +1221,8 @@ int cvx_image_plan_tile_out(const cvx_image_plan *plan, void *localStore, uint64
 static int ImageGatherLaunch(cvx_context *ctx, const cvx_image_plan *plan, void *hipStream, int unpack, const void *localStore, void *sendStream, const void *recvStream, void *images)
 {
 	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
-	if (!plan || !images) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "plan / images missing"); }
+	// (`images` is written only for frames this rank displays: a rank that displays none -- fewer frames than ranks -- may pass NULL)
+	if (!plan || (!images && plan->imagesMine > 0)) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "plan / images missing"); }
 	CVX_HIP(ctx, hipSetDevice(ctx->device));
 	hipStream_t st = hipStream ? (hipStream_t)hipStream : ctx->stream;
 	hipLaunchKernelGGL(cvxk::image_gather_kernel, dim3((unsigned)plan->H, (unsigned)plan->frameCount), dim3(CVX_WAVE), 0, st, plan->devFrames, plan->worldSize, plan->rank, unpack,

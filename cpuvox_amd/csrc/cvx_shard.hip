@@ -7,7 +7,27 @@
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
+// RCCL's own header types the entry points (a prototype that drifts is a compile error).  A host that has the runtime library but not the
+// development headers still builds the product: the handful of declarations this file uses, as RCCL 2.x publishes them.
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0, ncclUnhandledCudaError = 1, ncclSystemError = 2, ncclInternalError = 3, ncclInvalidArgument = 4, ncclInvalidUsage = 5, ncclRemoteError = 6, ncclInProgress = 7 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1 } ncclDataType_t;
+ncclResult_t ncclGetUniqueId(ncclUniqueId *uniqueId);
+ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId commId, int rank);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclCommAbort(ncclComm_t comm);
+ncclResult_t ncclGroupStart(void);
+ncclResult_t ncclGroupEnd(void);
+ncclResult_t ncclSend(const void *sendbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclRecv(void *recvbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream);
+const char *ncclGetErrorString(ncclResult_t result);
+}
+#endif
 
 #include <cmath>
 #include <chrono>

@@ -182,7 +182,9 @@ int cvx_shard_plan_tile_out(const cvx_shard_plan *plan, void *sendBase, void *di
 int cvx_comm_unique_id(void *id128);
 int cvx_comm_create(cvx_context *ctx, const void *id128, int rank, int worldSize, void **comm);
 /* ... with an explicit limit on how long to wait for the peers (cvx_comm_create waits 180 s): CVX_ERR_TIMEOUT when a rank of
- * the clique never arrives -- the sharded `render.Complete()` (RenderManager.cs:363) must not hang for ever on a dead peer. */
+ * the clique never arrives -- the sharded `render.Complete()` (RenderManager.cs:363) must not hang for ever on a dead peer.
+ * After CVX_ERR_TIMEOUT the helper thread that called ncclCommInitRank is still parked inside RCCL (it cannot be cancelled) and
+ * owns a half-made communicator: the process must report the failure and EXIT, not go on using the library. */
 int cvx_comm_create_timeout(cvx_context *ctx, const void *id128, int rank, int worldSize, double timeoutSeconds, void **comm);
 int cvx_comm_destroy(void *comm);
 /* The exchange of one batch on hipStream (NULL = the context's stream): returns after enqueueing; order the consumer with the stream. */
@@ -212,6 +214,7 @@ int64_t cvx_image_plan_tile_count(const cvx_image_plan *plan);
 int cvx_image_plan_sizes(const cvx_image_plan *plan, int64_t *localStoreBytes, int64_t *sendPixels, int64_t *recvPixels, int32_t *imagesDisplayed);
 int cvx_image_plan_transfer(const cvx_image_plan *plan, int peer, int64_t *sendPixel, int64_t *sendPixels, int64_t *recvPixel, int64_t *recvPixels);
 int cvx_image_plan_tile_out(const cvx_image_plan *plan, void *localStore, uint64_t *tileOut);
+/* (`images`: imagesDisplayed x H x W pixels; may be NULL on a rank that displays no frame of the batch, imagesDisplayed == 0) */
 int cvx_image_pack(cvx_context *ctx, const cvx_image_plan *plan, void *hipStream, const void *localStore, void *sendStream, void *images);
 int cvx_image_exchange(cvx_context *ctx, const cvx_image_plan *plan, void *comm, void *hipStream, void *sendStream, void *recvStream);
 int cvx_image_unpack(cvx_context *ctx, const cvx_image_plan *plan, void *hipStream, const void *recvStream, void *images);

@@ -198,6 +198,51 @@ def blit_reference(frame, td: np.ndarray, lr: np.ndarray, width: int, height: in
     return img
 
 
+def blit_reference_f64(frame, td: np.ndarray, lr: np.ndarray, width: int, height: int, clear: int = 0):
+    """Independent statement of the Phase-2 rule in float64 with plain barycentric weights (three cross products divided by the triangle's doubled
+    area: none of blit_reference's / the kernel's float32 edge-function arithmetic).  Returns (image, margin): margin[y, x] = the smallest |weight|
+    over the four segments' triangles at that pixel centre -- pixels with a margin above ~1e-4 cannot be assigned differently by float32 rounding, so
+    the GPU image has to equal this one there (the float32 reference and the kernel share their formula)."""
+    img = np.full((height, width), clear, dtype=np.uint32)
+    done = np.zeros((height, width), dtype=bool)
+    margin = np.full((height, width), np.inf)
+    ys, xs = np.mgrid[0:height, 0:width]
+    cx, cy = xs + 0.5, ys + 0.5
+    ax, ay = float(frame.vanishingPointScreenSpace[0]), float(frame.vanishingPointScreenSpace[1])
+    for s in range(4):
+        seg = frame.segments[s]
+        rcount = seg.RayCount
+        if rcount <= 0:
+            continue
+        bx, by = float(seg.MaxScreen[0]), float(seg.MaxScreen[1])
+        qx, qy = float(seg.MinScreen[0]), float(seg.MinScreen[1])
+        area = (bx - ax) * (qy - ay) - (qx - ax) * (by - ay)
+        if area == 0.0:
+            continue
+        # weights of a (the vanishing point), b (MaxScreen), q (MinScreen)
+        w_a = ((bx - cx) * (qy - cy) - (qx - cx) * (by - cy)) / area
+        w_b = ((qx - cx) * (ay - cy) - (ax - cx) * (qy - cy)) / area
+        w_q = 1.0 - w_a - w_b
+        margin = np.minimum(margin, np.minimum(np.abs(w_a), np.minimum(np.abs(w_b), np.abs(w_q))))
+        inside = (w_a >= 0) & (w_b >= 0) & (w_q >= 0) & ~done
+        with np.errstate(divide="ignore", invalid="ignore"):
+            x = w_b / (w_b + w_q)
+        ray = np.clip(np.floor(x * rcount), 0, rcount - 1)
+        ray = np.where(np.isfinite(ray), ray, 0).astype(np.int64)
+        # a pixel whose ray coordinate sits on a ray boundary may pick the neighbouring ray in float32: part of the margin
+        with np.errstate(invalid="ignore"):
+            frac = x * rcount - np.floor(x * rcount)
+        margin = np.where(inside, np.minimum(margin, np.minimum(frac, 1.0 - frac) / max(1, rcount) * 8.0), margin)
+        offset = frame.segments[0].RayCount if s == 1 else (frame.segments[2].RayCount if s == 3 else 0)
+        if s < 2:
+            vals = td[np.clip(ray + offset, 0, td.shape[0] - 1), ys]
+        else:
+            vals = lr[np.clip(ray + offset, 0, lr.shape[0] - 1), xs]
+        img[inside] = vals[inside]
+        done |= inside
+    return img, margin
+
+
 def argb_to_rgb8(img: np.ndarray) -> np.ndarray:
     """uint32 ARGB32 (bytes A,R,G,B in memory) -> uint8[..., 3] RGB."""
     b = img.view(np.uint8).reshape(img.shape + (4,))

@@ -175,6 +175,12 @@ def test_blit_matches_pixel_centre_rule(contexts):
         img = ctx.blit_segments(0)
         ref = O.blit_reference(fr, g_td, g_lr, W, H, clear=0)
         assert (img == ref).all(), f"{name}: {(img != ref).sum()} screen pixels differ"
+        # ... and an independent check (float64 barycentrics, none of the kernel's edge-function arithmetic): the images may differ only where a
+        # weight or a ray coordinate lies within rounding distance of a boundary, and those pixels are a sliver of the screen
+        ref64, margin = O.blit_reference_f64(fr, g_td, g_lr, W, H, clear=0)
+        differ = img != ref64
+        assert not (differ & (margin > 1e-4)).any(), f"{name}: {(differ & (margin > 1e-4)).sum()} pixels away from every boundary differ from the float64 rule"
+        assert differ.mean() < 2e-3, f"{name}: {differ.sum()} pixels differ from the float64 rule"
 
 
 def test_batch_blit_equals_single_blits():
