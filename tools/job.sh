@@ -1,13 +1,4 @@
 #!/bin/bash
-R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r04o; mkdir -p $O; cd $R
-timeout 600 python3 -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "downsample or device_built" 2>&1 | tail -3
-cd /tmp
-for L in libcpuvox_gpu_ds0.so libcpuvox_gpu_ds2k.so libcpuvox_gpu.so libcpuvox_gpu_ds4k.so; do
-  echo "== $L"; CVX_GPU_LIB=$R/cpuvox_amd/$L timeout 600 python3 $R/tools/downsample_bench.py 2048 2> $O/$L.err | python3 -c "
-import sys,json
-for l in sys.stdin:
-    d=json.loads(l)
-    if 'lod' in d: print('  lod',d['lod'],'device_ms',d['device_ms'],'identical',d['identical_to_host_build'])
-    else: print('  chain device_ms',d['build_lods_device_ms'])
-"
-done 2>&1 | tee $O/ds_ab.log
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r04r; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
+hipcc --offload-arch=gfx950 -O2 -o /tmp/valu_rate $R/tools/valu_rate.hip 2> $O/valu_build.log || { tail $O/valu_build.log; exit 1; }
+timeout -k 10 600 /tmp/valu_rate mix_ > $O/valu_rate_mix2.txt 2> $O/valu_rate.err; echo "valu_rate rc=$?"; cat $O/valu_rate_mix2.txt | grep -v "^lanes\|^[ 0-9]* low\|^[ 0-9]* spread\|active lanes"

@@ -126,6 +126,22 @@ struct WaveRec {
 	                          "v_cmp_lt_f32 s[22:23], %8, %4\n v_add_f32 %5, %8, %5\n v_cndmask_b32_e64 %6, %8, %9, s[22:23]\n v_add_f32 %7, %8, %7\n")) \
 	X(mix_cmp_cnd_e32, "", T2("v_cmp_lt_f32 vcc, %8, %0\n v_add_f32 %1, %8, %1\n v_cndmask_b32 %2, %8, %9, vcc\n v_add_f32 %3, %8, %3\n"           \
 	                          "v_cmp_lt_f32 vcc, %8, %4\n v_add_f32 %5, %8, %5\n v_cndmask_b32 %6, %8, %9, vcc\n v_add_f32 %7, %8, %7\n"))         \
+	X(mix_rcp, "", T2("v_rcp_f32 %0, %0\n v_add_f32 %1, %8, %1\n v_add_f32 %2, %8, %2\n v_add_f32 %3, %8, %3\n"                                    \
+	                  "v_rcp_f32 %4, %4\n v_add_f32 %5, %8, %5\n v_add_f32 %6, %8, %6\n v_add_f32 %7, %8, %7\n"))                                     \
+	X(mix_div_scale, "", T2("v_div_scale_f32 %0, vcc, %8, %9, %8\n v_add_f32 %1, %8, %1\n v_add_f32 %2, %8, %2\n v_add_f32 %3, %8, %3\n"            \
+	                        "v_div_fixup_f32 %4, %4, %8, %9\n v_add_f32 %5, %8, %5\n v_add_f32 %6, %8, %6\n v_add_f32 %7, %8, %7\n"))               \
+	X(mix_snop, "", T2("s_nop 0\n v_add_f32 %1, %8, %1\n v_add_f32 %2, %8, %2\n v_add_f32 %3, %8, %3\n"                                          \
+	                   "s_nop 0\n v_add_f32 %5, %8, %5\n v_add_f32 %6, %8, %6\n v_add_f32 %7, %8, %7\n"))                                           \
+	X(mix_waitcnt, "", T2("s_waitcnt vmcnt(0)\n v_add_f32 %1, %8, %1\n v_add_f32 %2, %8, %2\n v_add_f32 %3, %8, %3\n"                            \
+	                      "s_waitcnt lgkmcnt(0)\n v_add_f32 %5, %8, %5\n v_add_f32 %6, %8, %6\n v_add_f32 %7, %8, %7\n"))                           \
+	X(mix_salu2, "", T2("s_and_b64 s[20:21], s[20:21], s[22:23]\n s_or_b64 s[24:25], s[24:25], s[26:27]\n v_add_f32 %2, %8, %2\n v_add_f32 %3, %8, %3\n" \
+	                    "s_andn2_b64 s[22:23], s[22:23], s[24:25]\n s_xor_b64 s[26:27], s[26:27], s[20:21]\n v_add_f32 %6, %8, %6\n v_add_f32 %7, %8, %7\n")) \
+	X(mix_saveexec, "", T2("v_cmp_lt_f32 vcc, %8, %0\n s_and_saveexec_b64 s[20:21], vcc\n v_add_f32 %2, %8, %2\n s_or_b64 exec, exec, s[20:21]\n"    \
+	                       "v_add_f32 %4, %8, %4\n v_add_f32 %5, %8, %5\n v_add_f32 %6, %8, %6\n v_add_f32 %7, %8, %7\n"))                         \
+	X(mix_pk_fma, "", "v_add_f32 %0, %8, %0\n v_add_f32 %1, %8, %1\n v_add_f32 %2, %8, %2\n v_add_f32 %3, %8, %3\n v_add_f32 %4, %8, %4\n v_add_f32 %5, %8, %5\n v_pk_fma_f32 %[p0], %[p2], %[p2], %[p0]\n v_add_f32 %7, %8, %7\n" \
+	                  "v_add_f32 %0, %8, %0\n v_add_f32 %1, %8, %1\n v_add_f32 %2, %8, %2\n v_add_f32 %3, %8, %3\n v_add_f32 %4, %8, %4\n v_add_f32 %5, %8, %5\n v_pk_fma_f32 %[p1], %[p2], %[p2], %[p1]\n v_add_f32 %7, %8, %7\n") \
+	X(mix_lds, "", T2("ds_read_b32 %0, %[a]\n v_add_f32 %1, %8, %1\n v_add_f32 %2, %8, %2\n v_add_f32 %3, %8, %3\n"                               \
+	                  "ds_read_b32 %4, %[a]\n v_add_f32 %5, %8, %5\n v_add_f32 %6, %8, %6\n v_add_f32 %7, %8, %7\n") "s_waitcnt lgkmcnt(0)\n")    \
 	X(mix_add_only, "", T2(D8("v_add_f32 ", ", %8, ")))                                                                            \
 	/* scalar side */                                                                                                           \
 	X(salu_and, "", "s_and_b64 s[20:21], s[20:21], s[22:23]\n s_or_b64 s[22:23], s[22:23], s[24:25]\n s_and_b64 s[24:25], s[24:25], s[26:27]\n s_or_b64 s[26:27], s[26:27], s[20:21]\n" \
@@ -178,25 +194,28 @@ __device__ __forceinline__ unsigned long long shadertime()
 
 // `active` < 64: only that many lanes of every wave run the loop (the rest wait at the end)
 template <int KIND>
-__global__ __launch_bounds__(1024) void k(WaveRec *recs, float *out, float seed, int iters, int active)
+__global__ __launch_bounds__(1024) void k(WaveRec *recs, float *out, float seed, int iters, int active, int spread = 0)
 {
 	extern __shared__ unsigned ldsPad[];
 	const int lane = threadIdx.x & 63;
 	float a0 = seed + lane, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
 	float m = 1.0000001f + seed * 1e-9f, c = 1e-9f + seed;
+	double pd0 = a0, pd1 = a1, pd2 = m; // register pairs for the packed form
+	const unsigned ldsAddr = (threadIdx.x & 1023u) * 4u;
 	if (seed == 12345.f) { ldsPad[threadIdx.x] = 1u; }
 	// the "written by the scalar unit long ago" masks: an alternating lane pattern
 	asm volatile("s_mov_b64 s[22:23], 0x55555555\n s_mov_b64 s[24:25], 0x33333333\n s_mov_b64 s[26:27], -1\n s_mov_b64 s[20:21], 0" ::: "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");
 	__syncthreads();
 	unsigned long long t0 = 0, r0 = 0;
-	if (lane < active) {
+	const bool on = spread ? ((lane * active) >> 6) != (((lane - 1) * active) >> 6) || lane == 0 : lane < active; // spread: `active` lanes at even distances
+	if (on) {
 		t0 = shadertime();
 		r0 = realtime();
 		for (int i = 0; i < iters; i++) {
 #define X(name, pre, text)                                                                                                        \
 	if (KIND == K_##name) {                                                                                                       \
-		asm volatile(pre text text text text : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)     \
-		             : "v"(m), "v"(c)                                                                                             \
+		asm volatile(pre text text text text : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) \
+		             : "v"(m), "v"(c), [p2] "v"(pd2), [a] "v"(ldsAddr), [p0] "v"(pd0), [p1] "v"(pd1) /* (p0 / p1 are written by the packed test: timing only) */ \
 		                          : "vcc", "scc", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27");                                      \
 	}
 			BODY_LIST(X)
@@ -215,7 +234,7 @@ __global__ __launch_bounds__(1024) void k(WaveRec *recs, float *out, float seed,
 			recs[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = r;
 		}
 	}
-	out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+	out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(pd0 + pd1);
 }
 
 static int instructionsPerTrip(const char *pre, const char *text)
@@ -232,7 +251,7 @@ struct Result {
 };
 
 template <int KIND>
-Result run(const char *pre, const char *text, WaveRec *dRecs, float *dOut, int cus, int wavesPerSimd, int active)
+Result run(const char *pre, const char *text, WaveRec *dRecs, float *dOut, int cus, int wavesPerSimd, int active, int spread = 0)
 {
 	// workgroups: W <= 4: one of 256 W threads per CU; 6: two of 768; 8: two of 1024
 	const int perCu = wavesPerSimd <= 4 ? 1 : 2;
@@ -243,8 +262,8 @@ Result run(const char *pre, const char *text, WaveRec *dRecs, float *dOut, int c
 	(void)hipFuncSetAttribute((const void *)k<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
 	const int waves = blocks * threads / 64;
 	(void)hipMemset(dRecs, 0, sizeof(WaveRec) * (size_t)waves);
-	hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(threads), ldsBytes, 0, dRecs, dOut, 1.0f, 200, active); // warm-up
-	hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(threads), ldsBytes, 0, dRecs, dOut, 1.0f, iters, active);
+	hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(threads), ldsBytes, 0, dRecs, dOut, 1.0f, 200, active, spread); // warm-up
+	hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(threads), ldsBytes, 0, dRecs, dOut, 1.0f, iters, active, spread);
 	if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed: %s\n", hipGetErrorString(hipGetLastError())); return { 0, 0, 0, 0 }; }
 	std::vector<WaveRec> recs(waves);
 	(void)hipMemcpy(recs.data(), dRecs, sizeof(WaveRec) * (size_t)waves, hipMemcpyDeviceToHost);
@@ -301,13 +320,26 @@ int main(int argc, char **argv)
 	BODY_LIST(X)
 #undef X
 	if (strstr("lanes", filter) || !*filter) {
-		printf("\nactive lanes per wave (v_fma_f32, independent), cycles per instruction per SIMD (clock)\n%-18s", "lanes");
+		printf("\nactive lanes per wave, cycles per instruction per SIMD (clock): rows = active lanes, the low ones / spread evenly over the wave\n%-22s", "lanes, instruction");
 		for (int w : { 1, 2, 4 }) { printf(" %d wave(s)/SIMD     ", w); }
 		printf("\n");
-		for (int active : { 64, 32, 16, 8, 1 }) {
-			printf("%-18d", active);
+		for (int spread : { 0, 1 })
+		for (int active : { 64, 48, 32, 24, 20, 17, 16, 15, 14, 12, 10, 9, 8, 4, 1 }) {
+			char label[64];
+			snprintf(label, sizeof label, "%2d %s fma", active, spread ? "spread" : "low");
+			printf("%-22s", label);
 			for (int w : { 1, 2, 4 }) {
-				const Result r = run<K_fma>("", T2(D8("v_fma_f32 ", ", %8, %9, ")), dRecs, dOut, cus, w, active);
+				const Result r = run<K_fma>("", T2(D8("v_fma_f32 ", ", %8, %9, ")), dRecs, dOut, cus, w, active, spread);
+				printf(" %5.2f (%4.0f)      ", r.cyclesPerInstSimd, r.mhz);
+			}
+			printf("\n");
+		}
+		for (int active : { 64, 16, 12, 8, 4 }) {
+			char label[64];
+			snprintf(label, sizeof label, "%2d low add / cmp_e64 mix", active);
+			printf("%-22s", label);
+			for (int w : { 1, 2, 4 }) {
+				const Result r = run<K_mix_cmp_e64>("", "x\nx\nx\nx\nx\nx\nx\nx\nx\nx\nx\nx\nx\nx\nx\nx\n", dRecs, dOut, cus, w, active, 0);
 				printf(" %5.2f (%4.0f)      ", r.cyclesPerInstSimd, r.mhz);
 			}
 			printf("\n");
