@@ -672,9 +672,9 @@ def find_counter_summary(args):
         return None  # another build of the ABI was selected: no committed counters belong to it
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     try:
-        from pmc_aggregate import kernel_sources_sha256, library_sha256
+        from pmc_aggregate import library_sha256
 
-        mine, mine_lib = kernel_sources_sha256(), library_sha256(gpu.lib_path())
+        mine_lib = library_sha256(gpu.lib_path())
     except Exception:  # noqa: BLE001
         return None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_render_kernel*.csv")), reverse=True):
@@ -691,7 +691,7 @@ def find_counter_summary(args):
             same = all((getattr(theirs, k) if getattr(theirs, k) is not None else parse_default(k)) == getattr(args, k)
                        for k in ("frames", "width", "height", "world", "lod_error", "pose_range", "steps", "warmup"))
             # the library ITSELF must be the one the counters were collected with (the build is deterministic), not just its sources
-            if stamp.get("kernel_sources_sha256") == mine and stamp.get("library_sha256") == mine_lib and same:
+            if stamp.get("library_sha256") == mine_lib and same:  # (the sources' hash is in the stamp for the record; a comment edit does not change the library)
                 return path
         except (OSError, ValueError):
             continue

