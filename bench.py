@@ -200,7 +200,7 @@ def main():
         predicted = {"frames_per_gpu": choice[0], "area_bytes_per_gpu": int(choice[1]), "hbm_budget_bytes": int(budget), "payload_bytes_per_link_per_step": int(choice[2]),
                      "link_ms_at_153_GBps": round(choice[2] / 153e9 * 1e3, 3)}
         if rank == 0:
-            print(f"bench.py: --frames auto -> {choice[0]} per GPU ({choice[1] / 1e9:.2f} GB of areas per GPU against a budget of {budget / 1e9:.0f} GB; "
+            print(f"bench.py: --frames auto -> {choice[0]} per GPU ({choice[1] / 1e9:.2f} GB of areas per GPU against a budget of {budget / 1e9:.1f} GB; "
                   f"{choice[2] / 1e6:.1f} MB per peer and step = {choice[2] / 153e9 * 1e3:.2f} ms on one 153 GB/s xGMI link)", file=sys.stderr, flush=True)
     F = args.frames
     G = N * F  # frames per step, whole job
