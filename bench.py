@@ -554,9 +554,9 @@ def main():
 
     parity_frames = []
     if N == 1:
-        # what the GPU rendered for two frames of the LAST timed step (compared with the CPU oracle in the cpu_baseline leg below)
+        # what the GPU rendered for eight frames spread over the LAST timed step (compared with the CPU oracle in the cpu_baseline leg below)
         last = steps_frames[total_steps - 1]
-        for b in sorted({0, F // 2}):
+        for b in sorted({(F * i) // 8 for i in range(8)}):
             rc = [max(0, sg.RayCount) for sg in last[b].segments]
             parity_frames.append((b, last[b], ctx.read_raybuffer(b, gpu.RAYBUFFER_TOPDOWN, 0, rc[0] + rc[1]),
                                   ctx.read_raybuffer(b, gpu.RAYBUFFER_LEFTRIGHT, 0, rc[2] + rc[3])))
