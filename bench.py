@@ -672,6 +672,7 @@ def find_counter_summary(args):
         return None  # another build of the ABI was selected: no committed counters belong to it
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     try:
+        from cpuvox_amd import gpu
         from pmc_aggregate import library_sha256
 
         mine_lib = library_sha256(gpu.lib_path())

@@ -153,3 +153,29 @@ def test_exchange_entry_points_fail_cleanly_without_a_device_or_peers():
     assert L.cvx_comm_unique_id(None) == -1
     assert L.cvx_comm_destroy(None) == 0
     assert L.cvx_shard_plan_tile_count(None) == 0
+
+
+def test_bench_attaches_the_committed_counter_summary_of_this_library():
+    """bench.py's `roofline.traffic` comes from profiles/rNN_pmc_render_kernel*.csv, matched by the sha-256 of the library it loads and by the workload
+    arguments.  When the tree's library is the one the newest profiles were collected with, the default workload must find its file
+    (round 4: the lookup referenced a name that did not exist at module level and silently returned None)."""
+    import argparse
+    import importlib.util
+    import json
+
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    sys_path = os.path.join(ROOT, "tools")
+    import sys
+    sys.path.insert(0, sys_path)
+    from pmc_aggregate import library_sha256
+
+    newest = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("_pmc_render_kernel.csv"))[-1]
+    stamp = json.loads(open(os.path.join(ROOT, "profiles", newest)).readline()[1:])
+    args = argparse.Namespace(frames=512, width=1920, height=1080, world="proc2048", lod_error=1.0, pose_range=None, steps=10, warmup=2)
+    found = bench.find_counter_summary(args)
+    if stamp.get("library_sha256") == library_sha256(gpu.lib_path()):
+        assert found and os.path.basename(found) == newest, found
+    else:
+        assert found is None or os.path.basename(found) != newest  # another build: its counters are not this library's
