@@ -527,11 +527,10 @@ def main():
         # scattered 4-, 16- or 32-byte access, and FETCH_SIZE tallies each at 64 bytes -- so fetched bytes = 128 x TCC_EA0_RDREQ_128B + 64 x (the
         # 64-byte requests) + 32 x TCC_EA0_RDREQ_32B when the summary holds those counters, else 2 x FETCH_SIZE (the same number when all requests
         # are 128-byte ones, which is what this kernel produces).  WRITE_SIZE is exact.
-        import csv
-
         try:
-            with open(args.pmc_csv, newline="") as fh:
-                counters = {row["counter"]: float(row["mean_per_launch"]) for row in csv.DictReader(l for l in fh if not l.startswith("#"))}
+            counters = read_counter_summary(args.pmc_csv, args.warmup, args.steps)
+            if counters is None:
+                raise ValueError("its launches do not cover the timed steps of this run")
             fetch_raw, write = counters["FETCH_SIZE"] * 1024, counters["WRITE_SIZE"] * 1024
             if all(k in counters for k in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_128B_sum")):
                 n, n32, n128 = counters["TCC_EA0_RDREQ_sum"], counters["TCC_EA0_RDREQ_32B_sum"], counters["TCC_EA0_RDREQ_128B_sum"]
@@ -662,10 +661,46 @@ def main():
         raise SystemExit("bench.py: the GPU raybuffers of the timed frames differ from the CPU oracle")
 
 
+def read_counter_summary(path, warmup, steps):
+    """{counter: mean per launch over the TIMED steps [warmup, warmup + steps)} from a tools/pmc_aggregate.py summary, or None when the
+    summary cannot speak for those steps.  Launch i of a bench.py run is step i (warm-up first) and a step's frames depend on its index
+    only, so a summary that lists every launch (`per_launch` column, round 5) serves any --steps / --warmup its launches cover -- the
+    driver's 20 / 5 as well as the default 10 / 2.  A summary without that column (rounds 1-4) only holds the mean over the timed
+    steps of the run that collected it: usable for exactly the same --steps / --warmup."""
+    import csv
+
+    with open(path, newline="") as fh:
+        first = fh.readline()
+        stamp = json.loads(first[1:]) if first.startswith("#") else {}
+        rows = list(csv.DictReader(l for l in ([] if first.startswith("#") else [first]) + fh.readlines() if not l.startswith("#")))
+    theirs = stamped_bench_args(stamp)
+    out = {}
+    for row in rows:
+        series = [float(v) for v in (row.get("per_launch") or "").split(";") if v]
+        if series:
+            if len(series) != theirs["steps"] + theirs["warmup"] or warmup + steps > len(series):
+                return None  # (other launches were counted too, e.g. latency legs, or the run was shorter than this one)
+            out[row["counter"]] = sum(series[warmup:warmup + steps]) / steps
+        elif (theirs["steps"], theirs["warmup"]) == (steps, warmup):
+            out[row["counter"]] = float(row["mean_per_launch"])
+        else:
+            return None
+    return out or None
+
+
+def stamped_bench_args(stamp):
+    """The workload arguments of the bench.py runs a counter summary was collected with (defaults filled in)."""
+    ap = argparse.ArgumentParser()
+    for flag, typ in (("--frames", int), ("--width", int), ("--height", int), ("--world", str), ("--lod-error", float), ("--pose-range", str), ("--steps", int), ("--warmup", int)):
+        ap.add_argument(flag, type=typ, default=None)
+    theirs, _ = ap.parse_known_args(stamp.get("bench_args", []))
+    return {k: (getattr(theirs, k) if getattr(theirs, k) is not None else parse_default(k)) for k in ("frames", "width", "height", "world", "lod_error", "pose_range", "steps", "warmup")}
+
+
 def find_counter_summary(args):
-    """profiles/rNN_pmc_render_kernel.csv of THIS build and THIS workload, or None.  tools/profile_round.sh stamps the file with the
-    sha-256 of the kernel sources and the bench arguments of the counter passes (tools/pmc_aggregate.py); counters of another
-    build or of another shape are never attached to the line (roofline.traffic stays null)."""
+    """profiles/rNN_pmc_render_kernel*.csv of THIS build and THIS workload whose launches cover the timed steps of this run, or None.
+    tools/profile_round.sh stamps the file with the sha-256 of the library the counter passes loaded and with their bench arguments
+    (tools/pmc_aggregate.py); counters of another build or of another shape are never attached to the line (roofline.traffic stays null)."""
     import glob
 
     if os.environ.get("CVX_GPU_LIB"):
@@ -685,16 +720,12 @@ def find_counter_summary(args):
             if not first.startswith("#"):
                 continue
             stamp = json.loads(first[1:])
-            ap = argparse.ArgumentParser()
-            for flag, typ in (("--frames", int), ("--width", int), ("--height", int), ("--world", str), ("--lod-error", float), ("--pose-range", str), ("--steps", int), ("--warmup", int)):
-                ap.add_argument(flag, type=typ, default=None)
-            theirs, _ = ap.parse_known_args(stamp.get("bench_args", []))
-            same = all((getattr(theirs, k) if getattr(theirs, k) is not None else parse_default(k)) == getattr(args, k)
-                       for k in ("frames", "width", "height", "world", "lod_error", "pose_range", "steps", "warmup"))
+            theirs = stamped_bench_args(stamp)
+            same = all(theirs[k] == getattr(args, k) for k in ("frames", "width", "height", "world", "lod_error", "pose_range"))
             # the library ITSELF must be the one the counters were collected with (the build is deterministic), not just its sources
-            if stamp.get("library_sha256") == mine_lib and same:  # (the sources' hash is in the stamp for the record; a comment edit does not change the library)
+            if stamp.get("library_sha256") == mine_lib and same and read_counter_summary(path, args.warmup, args.steps) is not None:
                 return path
-        except (OSError, ValueError):
+        except (OSError, ValueError, KeyError):
             continue
     return None
 

@@ -179,3 +179,52 @@ def test_bench_attaches_the_committed_counter_summary_of_this_library():
         assert found and os.path.basename(found) == newest, found
     else:
         assert found is None or os.path.basename(found) != newest  # another build: its counters are not this library's
+
+
+def test_counter_summary_serves_the_drivers_argument_vector(tmp_path, monkeypatch):
+    """the driver runs `bench.py --gpus 1 --steps 20 --warmup 5`, the builder's default is 10 / 2 -- and round 4's summary,
+    collected with the default, was refused for the driver's line (`roofline.traffic: null`).  A summary now lists every launch, bench.py takes
+    the mean over the timed steps of ITS run; both argument vectors must find the file, a longer run than the collected one must not."""
+    import importlib.util
+    import json
+    import sys
+
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from pmc_aggregate import library_sha256
+
+    (tmp_path / "profiles").mkdir()
+    stamp = {"kernel_sources_sha256": "x", "library_sha256": library_sha256(gpu.lib_path()),
+             "bench_args": ["--cpu-seconds", "0", "--latency-frames", "0", "--steps", "20", "--warmup", "5"]}
+    fetch = [1000.0 + i for i in range(25)]
+    write = [10.0 * (i % 2) for i in range(25)]
+    with open(tmp_path / "profiles" / "r99_pmc_render_kernel.csv", "w") as fh:
+        fh.write("# " + json.dumps(stamp) + "\n")
+        fh.write("counter,mean_per_launch,launches,per_launch\n")
+        fh.write("FETCH_SIZE,%g,25,%s\n" % (sum(fetch) / 25, ";".join("%.9g" % v for v in fetch)))
+        fh.write("WRITE_SIZE,%g,25,%s\n" % (sum(write) / 25, ";".join("%.9g" % v for v in write)))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.delenv("CVX_GPU_LIB", raising=False)
+
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5"])  # the driver's command line, verbatim
+    args = bench.parse_args()
+    found = bench.find_counter_summary(args)
+    assert found and found.endswith("r99_pmc_render_kernel.csv"), found
+    c = bench.read_counter_summary(found, args.warmup, args.steps)
+    assert c["FETCH_SIZE"] == sum(fetch[5:25]) / 20 and c["WRITE_SIZE"] == sum(write[5:25]) / 20
+
+    monkeypatch.setattr(sys, "argv", ["bench.py"])  # the default run: steps 2 .. 11 of the same launches
+    args = bench.parse_args()
+    found = bench.find_counter_summary(args)
+    assert found, "the default --steps 10 --warmup 2 is covered by the 25 collected launches"
+    assert bench.read_counter_summary(found, args.warmup, args.steps)["FETCH_SIZE"] == sum(fetch[2:12]) / 10
+
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "30", "--warmup", "5"])  # longer than what was collected: no counters for steps 25 ..
+    assert bench.find_counter_summary(bench.parse_args()) is None
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "20", "--warmup", "5", "--width", "3840", "--height", "2160"])  # another workload
+    assert bench.find_counter_summary(bench.parse_args()) is None
+    # a summary of rounds 1-4 (no per-launch column) still serves exactly the run that collected it, nothing else
+    old = os.path.join(ROOT, "profiles", "r04_pmc_render_kernel.csv")
+    assert bench.read_counter_summary(old, 2, 10) is not None and bench.read_counter_summary(old, 5, 20) is None

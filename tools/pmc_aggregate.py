@@ -5,7 +5,10 @@ usage: tools/pmc_aggregate.py <pmc outdir> <kernel substring> [bench args of the
 (first line: a comment with the sha-256 of the kernel sources and the bench arguments the counters were collected with)
 
 For every counter: mean over the dispatches of kernels whose name contains the substring (counter values of one
-dispatch are summed over the rows rocprofv3 emits for it, e.g. one row per XCD/instance)."""
+dispatch are summed over the rows rocprofv3 emits for it, e.g. one row per XCD/instance), and -- fourth column -- the value of
+every single launch in dispatch order (`;`-separated).  Launch i of a bench.py run is its step i (warm-up steps first), and
+which frames a step renders depends on its index only, so bench.py can assemble the mean over the timed steps of ANY
+--steps / --warmup that the collected launches cover (round 5: the driver runs --steps 20 --warmup 5, the default is 10 / 2)."""
 import csv
 import glob
 import hashlib
@@ -44,15 +47,17 @@ def main():
                 if needle not in row["Kernel_Name"]:
                     continue
                 per_dispatch[(path, row["Dispatch_Id"], row["Counter_Name"])] += float(row["Counter_Value"])
-    sums, counts = defaultdict(float), defaultdict(int)
-    for (_, _, name), v in per_dispatch.items():
+    sums, counts, series = defaultdict(float), defaultdict(int), defaultdict(list)
+    for (path, dispatch, name), v in per_dispatch.items():
         sums[name] += v
         counts[name] += 1
+        series[name].append((path, int(dispatch), v))
     stamp = {"kernel_sources_sha256": kernel_sources_sha256(), "library_sha256": library_sha256(), "bench_args": sys.argv[3:]}
     print("# " + json.dumps(stamp))
-    print("counter,mean_per_launch,launches")
+    print("counter,mean_per_launch,launches,per_launch")
     for name in sums:
-        print(f"{name},{sums[name] / counts[name]:.6g},{counts[name]}")
+        per_launch = ";".join(f"{v:.9g}" for _, _, v in sorted(series[name]))  # (one pass = one process: dispatch ids ascend in launch order)
+        print(f"{name},{sums[name] / counts[name]:.6g},{counts[name]},{per_launch}")
 
 
 if __name__ == "__main__":

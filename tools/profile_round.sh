@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything profiles/rNN_* is made from, in one go on the GPU box: tools/profile_round.sh <tag, e.g. r02>
 # (kernel trace + stats, PMC passes, SQ stall / instruction counters of the default bench command; results under gpurun_out/<tag>/)
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -9,12 +9,16 @@ cd /tmp; export TMPDIR=/tmp
 # 1. kernel trace + stats of the default command (no CPU leg: the profiler would only see it as idle time)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$R/bench.py" --cpu-seconds 0 --latency-frames 0 > "$OUT/trace_bench.json" 2> "$OUT/trace.log"
 find "$OUT/trace" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats.csv" \;
-# 2. counter passes (separate runs, --pmc only)
-# (the default --steps / --warmup: the same frames as the bench line the summary is attached to)
-bash "$R/tools/pmc_passes.sh" "$OUT/pmc" --cpu-seconds 0 --latency-frames 0 > "$OUT/pmc_passes.log" 2>&1
-python3 "$R/tools/pmc_aggregate.py" "$OUT/pmc" "render_kernel<false>" --cpu-seconds 0 --latency-frames 0 > "$OUT/pmc_render_kernel.csv"
+# 2. counter passes (separate runs, --pmc only) with the DRIVER's step counts (every BENCH_rNN.json: --steps 20 --warmup 5): the summary lists every
+# launch, so bench.py assembles the timed steps of any run these 25 launches cover -- the default 10 / 2 as well (round 4 collected 10 / 2 and the
+# driver's line went without its traffic)
+DRV="--steps 20 --warmup 5"
+bash "$R/tools/pmc_passes.sh" "$OUT/pmc" --cpu-seconds 0 --latency-frames 0 $DRV > "$OUT/pmc_passes.log" 2>&1
+python3 "$R/tools/pmc_aggregate.py" "$OUT/pmc" "render_kernel<false>" --cpu-seconds 0 --latency-frames 0 $DRV > "$OUT/pmc_render_kernel.csv"
 # 3. the bench line of this build with the measured traffic attached (and the CPU leg, parity check, latency legs)
 timeout 900 python3 "$R/bench.py" --pmc-csv "$OUT/pmc_render_kernel.csv" > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
+# 3b. the driver's own command line, counters looked up as the driver's run will (no --pmc-csv: the file must first be copied to profiles/; here it is only a rehearsal of the timing)
+timeout 900 python3 "$R/bench.py" --gpus 1 $DRV --pmc-csv "$OUT/pmc_render_kernel.csv" > "$OUT/bench_driver_args.json" 2> "$OUT/bench_driver_args.err"
 # 4. SQ counters (128 frames per launch)
 bash "$R/tools/pmc_stalls.sh" libcpuvox_gpu.so > "$OUT/sq_counters.txt" 2>&1
 bash "$R/tools/pmc_insts.sh" libcpuvox_gpu.so >> "$OUT/sq_counters.txt" 2>&1
