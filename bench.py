@@ -196,8 +196,12 @@ def main():
             choice = (cand, area, per_link)
             if area <= budget:
                 break
+        else:  #  not even 8 frames per GPU fit: go on with 8 -- the smallest batch the bench runs -- and say so
+            if rank == 0:
+                print(f"bench.py: WARNING --frames auto: no candidate fits --hbm-budget-gb {args.hbm_budget_gb:g} ({choice[1] / 1e9:.2f} GB of areas per GPU "
+                      f"at {choice[0]} frames); running {choice[0]} frames per GPU OVER the budget", file=sys.stderr, flush=True)
         args.frames = choice[0]
-        predicted = {"frames_per_gpu": choice[0], "area_bytes_per_gpu": int(choice[1]), "hbm_budget_bytes": int(budget), "payload_bytes_per_link_per_step": int(choice[2]),
+        predicted = {"frames_per_gpu": choice[0], "area_bytes_per_gpu": int(choice[1]), "hbm_budget_bytes": int(budget), "fits_budget": bool(choice[1] <= budget), "payload_bytes_per_link_per_step": int(choice[2]),
                      "link_ms_at_153_GBps": round(choice[2] / 153e9 * 1e3, 3)}
         if rank == 0:
             print(f"bench.py: --frames auto -> {choice[0]} per GPU ({choice[1] / 1e9:.2f} GB of areas per GPU against a budget of {budget / 1e9:.1f} GB; "

@@ -96,17 +96,6 @@ struct cvx_context {
 	std::vector<int> hostTileWords;  // LDS mask words per lane the tile needs
 	int maskWordsNeeded = 1;         // LDS mask words per lane of the widest [origMin, origMax] window in the current launch
 	int ldsWordsNeeded = CVX_WAVE;   // LDS words (mask words x lanes) of the largest wave of the current launch
-	// LDS classes of the current draw (DrawBatch): the waves of a draw are grouped by the mask their window needs and every class is its own
-	// launch with its own dynamic-LDS size, on its own stream, so that ONE tall tile no longer sizes the LDS of every wave (a launch has one size).
-	// hostTiles holds class 0 first; launchClass[k] = {first wave, waves, LDS words of the largest wave}.
-	struct LaunchClass {
-		size_t first = 0, count = 0;
-		int ldsWords = CVX_WAVE;
-	};
-	static constexpr int kLaunchClasses = 3;
-	LaunchClass launchClass[kLaunchClasses];
-	hipStream_t classStream[kLaunchClasses - 1] = {}; // classes 1.. run beside class 0 (which runs on ctx->stream); created on first use
-	hipEvent_t classFork = nullptr, classJoin[kLaunchClasses - 1] = {};
 	int maxWaveMaskWords = 40 * CVX_WAVE; // LDS budget per wave: 10 KB = 16 waves per CU; wider tiles are cut into narrower waves
 	bool maxWaveMaskWordsAuto = true;     // ... chosen per launch by DrawBatch's cost model unless CVX_MAX_WAVE_MASK_WORDS pins it
 

@@ -419,43 +419,16 @@ int Launch(cvx_context *ctx, int frameCount, int flags)
 	if (rc != CVX_OK) { return rc; }
 	CVX_HIP(ctx, hipEventRecord(evStart, ctx->stream));
 	if (nTiles) {
-		// One launch per LDS class (DrawBatch), all frames of the batch in it: the iteration direction (RenderJob.Execute :174-178) is a wave-uniform
-		// runtime switch inside the kernel, so the tails of different frames overlap.  A launch has ONE dynamic-LDS size, the largest mask any of its
-		// waves needs; the classes run beside each other on streams of their own (workgroups of different launches share a CU), forked from and joined
-		// to ctx->stream by events, so the draw is still one unit of work on the caller's stream and the event pair around it times all of it.
-		int active = 0;
-		for (int c = 0; c < cvx_context::kLaunchClasses; c++) { active += ctx->launchClass[c].count ? 1 : 0; }
-		if (active > 1) {
-			if (!ctx->classFork) { CVX_HIP(ctx, hipEventCreateWithFlags(&ctx->classFork, hipEventDisableTiming)); }
-			CVX_HIP(ctx, hipEventRecord(ctx->classFork, ctx->stream));
+		// ONE launch, all frames of the batch in it: the iteration direction (RenderJob.Execute :174-178) is a wave-uniform runtime switch inside the
+		// kernel, so the tails of different frames overlap.  Its dynamic-LDS size is the largest mask any of its waves needs (DrawBatch).
+		const size_t ldsBytes = (size_t)std::max(ctx->ldsWordsNeeded, ctx->minMaskWords * CVX_WAVE) * sizeof(uint32_t);
+		dim3 grid((unsigned)nTiles), block(CVX_WAVE);
+		if (ctx->countersEnabled) {
+			hipLaunchKernelGGL((cvxk::render_kernel<true>), grid, block, ldsBytes, ctx->stream, ctx->devFrames, ctx->devTiles, ctx->devWorld, ctx->devCounters);
+		} else {
+			hipLaunchKernelGGL((cvxk::render_kernel<false>), grid, block, ldsBytes, ctx->stream, ctx->devFrames, ctx->devTiles, ctx->devWorld, ctx->devCounters);
 		}
-		int used = 0; // the first class with waves runs on ctx->stream itself
-		for (int c = 0; c < cvx_context::kLaunchClasses; c++) {
-			const cvx_context::LaunchClass &lc = ctx->launchClass[c];
-			if (!lc.count) { continue; }
-			hipStream_t stream = ctx->stream;
-			if (used > 0) {
-				hipStream_t &aux = ctx->classStream[used - 1];
-				if (!aux) { CVX_HIP(ctx, hipStreamCreateWithFlags(&aux, hipStreamNonBlocking)); }
-				if (!ctx->classJoin[used - 1]) { CVX_HIP(ctx, hipEventCreateWithFlags(&ctx->classJoin[used - 1], hipEventDisableTiming)); }
-				CVX_HIP(ctx, hipStreamWaitEvent(aux, ctx->classFork, 0));
-				stream = aux;
-			}
-			const size_t ldsBytes = (size_t)std::max(lc.ldsWords, ctx->minMaskWords * CVX_WAVE) * sizeof(uint32_t);
-			const DevTile *tiles = ctx->devTiles + lc.first;
-			dim3 grid((unsigned)lc.count), block(CVX_WAVE);
-			if (ctx->countersEnabled) {
-				hipLaunchKernelGGL((cvxk::render_kernel<true>), grid, block, ldsBytes, stream, ctx->devFrames, tiles, ctx->devWorld, ctx->devCounters);
-			} else {
-				hipLaunchKernelGGL((cvxk::render_kernel<false>), grid, block, ldsBytes, stream, ctx->devFrames, tiles, ctx->devWorld, ctx->devCounters);
-			}
-			CVX_HIP(ctx, hipGetLastError());
-			if (used > 0) {
-				CVX_HIP(ctx, hipEventRecord(ctx->classJoin[used - 1], stream));
-				CVX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->classJoin[used - 1], 0));
-			}
-			used++;
-		}
+		CVX_HIP(ctx, hipGetLastError());
 	}
 	CVX_HIP(ctx, hipEventRecord(evStop, ctx->stream));
 	if (!(flags & CVX_DRAW_ASYNC)) {
@@ -773,26 +746,13 @@ int DrawBatch(cvx_context *ctx, int frameCount, const cvx_segment_data *segments
 		// fitted to the sweeps in profiles/r02_occupancy.md: a wave of 64 / 32 / 16 / 8 ... lanes costs 1 / 0.68 / 0.40 / 0.25 ... of
 		// a full one, and throughput grows with (resident waves)^0.4 (at most 16 per CU: 128 VGPRs).  1080p picks 10 KB (every
 		// top / bottom tile stays whole), 4K picks 17 KB (68-word top / bottom tiles whole, left / right tiles halved).
-		// Round 4 built LDS classes: the waves of a draw grouped by the mask their window needs (<= 10 KB, <= 17 KB, more), every class a
-		// launch of its own with its own dynamic-LDS size on its own stream, so that a 68-word 4K tile would no longer put 17 KB on every wave of the draw.  The
-		// launches do run side by side (rocprofv3 kernel trace: both start within 7 us), and the draw is SLOWER: 4K / 2048^3 25.0 against 23.2 ms per 128 frames,
-		// 4K / 4096^3 11.4 against 10.6, 1080p with a class for the 41..60-word left / right tiles 16.7 against 13.2 (profiles/r04_experiments.md).  The kernel
-		// is bound by vector issue now (profiles/r04_issue_model.md), so 16 instead of 9 resident waves per CU buy nothing, while every class starts its
-		// longest tiles at once and the longest-first order across the draw is lost.  Kept behind -DCVX_EXP_LDS_CLASSES; the product makes ONE launch.
-		// Likewise measured: choosing the split per tile instead of by one budget per draw (-DCVX_EXP_PER_TILE_RULE), 3.6 % slower at 1080p.
+		// (Measured and archived, tools/patches/exp_lds_classes_and_per_tile_rule.patch + profiles/r04_experiments.md: one launch per mask-size class on
+		// streams of their own -- 4K / 2048^3 25.0 against 23.2 ms -- and a split chosen per tile instead of by one budget per draw: +3.6 % at 1080p.)
 		static const double laneCost[7] = { 1.0, 0.68, 0.40, 0.25, 0.16, 0.11, 0.08 }; // 64, 32, 16, 8, 4, 2, 1 lanes
-#ifdef CVX_EXP_LDS_CLASSES
-		static const int classLimit[cvx_context::kLaunchClasses] = { 40 * CVX_WAVE, 68 * CVX_WAVE, 1 << 30 }; // 10 KB (16 waves per CU), 17 KB (9), the rest
-#endif
 		auto residentWaves = [](int waveWords) { return std::max(1, std::min(16, (int)(163840 / ((size_t)waveWords * 4)))); };
 		int baseLevel = 0;
 		while ((1 << baseLevel) < split) { baseLevel++; }
-		// The split itself follows ONE budget per draw, chosen as in rounds 2 and 3 by the single-size model over these candidates (1080p: 10 KB, every top /
-		// bottom tile whole, the few wider left / right tiles halved; 4K: 17 KB): choosing per tile -- which keeps a 41..60-word left / right tile whole in a
-		// 15 KB class -- measured 3.6 % slower at 1080p (r04_experiments.md: such a wave is the longest-lived of the draw, and a draw is not over before its
-		// longest wave), and with a launch of its own for those tiles 26 % slower.
 		int budget = ctx->maxWaveMaskWords; // (diagnostics: CVX_MAX_WAVE_MASK_WORDS pins it)
-#ifndef CVX_EXP_PER_TILE_RULE
 		if (ctx->maxWaveMaskWordsAuto) {
 			static const int candidates[] = { 40 * CVX_WAVE, 48 * CVX_WAVE, 60 * CVX_WAVE, 68 * CVX_WAVE, 80 * CVX_WAVE, 96 * CVX_WAVE, 120 * CVX_WAVE, 160 * CVX_WAVE, 256 * CVX_WAVE };
 			double bestCost = 0.0;
@@ -808,42 +768,24 @@ int DrawBatch(cvx_context *ctx, int frameCount, const cvx_segment_data *segments
 				if (bestCost == 0.0 || cost < bestCost) { bestCost = cost; budget = candidate; }
 			}
 		}
-#endif
-		std::vector<DevTile> classTiles[cvx_context::kLaunchClasses];
-		int classWords[cvx_context::kLaunchClasses] = { 1, 1, 1 };
+		std::vector<DevTile> sorted;
+		sorted.reserve(n * (size_t)split);
 #ifdef CVX_TILE_TIMES
-		std::vector<uint32_t> classSource[cvx_context::kLaunchClasses];
+		g_waveSource.clear();
 		g_sourceTiles = n;
 #endif
+		int ldsWords = 1; // words * lanes of the largest wave
 		for (size_t i = 0; i < n; i++) {
 			DevTile t = ctx->hostTiles[order[i]];
 			const int words = ctx->hostTileWords[order[i]];
 			int tileSplit = split;
-#ifdef CVX_EXP_PER_TILE_RULE /* A/B partner: the split chosen per tile (measured slower, see above) */
-			if (ctx->maxWaveMaskWordsAuto) {
-#else
-			if (false) {
-#endif
-				double best = 0.0;
-				for (int s2 = split, level = baseLevel; s2 <= CVX_WAVE; s2 *= 2, level++) {
-					const int waveWords = words * (CVX_WAVE / s2);
-					if ((size_t)waveWords * 4 > 65536 && s2 < CVX_WAVE) { continue; } // (the dynamic-LDS limit of a launch without an opt-in attribute)
-					const double cost = (double)(s2 / split) * laneCost[level] / std::pow((double)residentWaves(waveWords), 0.4);
-					if (best == 0.0 || cost < best * 0.999) { best = cost; tileSplit = s2; }
-				}
-			} else {
-				while (tileSplit < CVX_WAVE && words * (CVX_WAVE / tileSplit) > budget) { tileSplit *= 2; }
-			}
+			while (tileSplit < CVX_WAVE && words * (CVX_WAVE / tileSplit) > budget) { tileSplit *= 2; }
 			const int lanesPerWave = CVX_WAVE / tileSplit;
-			int cls = 0;
-#ifdef CVX_EXP_LDS_CLASSES /* measured and lost (see above): one launch per LDS class */
-			while (cls + 1 < cvx_context::kLaunchClasses && words * lanesPerWave > classLimit[cls]) { cls++; }
-#endif
-			classWords[cls] = std::max(classWords[cls], words * lanesPerWave);
+			ldsWords = std::max(ldsWords, words * lanesPerWave);
 			if (tileSplit == 1) {
-				classTiles[cls].push_back(t);
+				sorted.push_back(t);
 #ifdef CVX_TILE_TIMES
-				classSource[cls].push_back(order[i]);
+				g_waveSource.push_back(order[i]);
 #endif
 				continue;
 			}
@@ -854,42 +796,11 @@ int DrawBatch(cvx_context *ctx, int frameCount, const cvx_segment_data *segments
 				int dupShift = 0;
 				while (!ctx->countersEnabled && (lanesPerWave << dupShift) < CVX_WAVE) { dupShift++; }
 				t.lanes = (k * lanesPerWave) | (lanesPerWave << 8) | (dupShift << 16);
-				classTiles[cls].push_back(t);
+				sorted.push_back(t);
 #ifdef CVX_TILE_TIMES
-				classSource[cls].push_back(order[i]);
+				g_waveSource.push_back(order[i]);
 #endif
 			}
-		}
-		// A class with only a handful of waves is not worth a launch of its own: folded into the next larger one
-		for (int c = 0; c + 1 < cvx_context::kLaunchClasses; c++) {
-			int next = c + 1;
-			while (next + 1 < cvx_context::kLaunchClasses && classTiles[next].empty()) { next++; }
-			if (!classTiles[c].empty() && !classTiles[next].empty() && classTiles[c].size() < 256) {
-				// (merged in LPT order: both lists are sorted by descending cost; merge by walking the original order is not kept per class, so append and
-				// let the few short waves of the small class run at the end)
-				classTiles[next].insert(classTiles[next].end(), classTiles[c].begin(), classTiles[c].end());
-				classWords[next] = std::max(classWords[next], classWords[c]);
-#ifdef CVX_TILE_TIMES
-				classSource[next].insert(classSource[next].end(), classSource[c].begin(), classSource[c].end());
-#endif
-				classTiles[c].clear();
-			}
-		}
-		std::vector<DevTile> sorted;
-		sorted.reserve(n * (size_t)split);
-#ifdef CVX_TILE_TIMES
-		g_waveSource.clear();
-#endif
-		int ldsWords = 1; // words * lanes of the largest wave
-		for (int c = 0; c < cvx_context::kLaunchClasses; c++) {
-			ctx->launchClass[c].first = sorted.size();
-			ctx->launchClass[c].count = classTiles[c].size();
-			ctx->launchClass[c].ldsWords = classWords[c];
-			sorted.insert(sorted.end(), classTiles[c].begin(), classTiles[c].end());
-#ifdef CVX_TILE_TIMES
-			g_waveSource.insert(g_waveSource.end(), classSource[c].begin(), classSource[c].end());
-#endif
-			if (!classTiles[c].empty()) { ldsWords = std::max(ldsWords, classWords[c]); }
 		}
 		ctx->ldsWordsNeeded = ldsWords;
 		ctx->hostTiles.swap(sorted);

@@ -28,11 +28,7 @@ namespace cvxk {
 // next column's record would be waited for by the first colour load or run-list load of the current column.  Saying
 // "global" (address space 1) gives global_load / global_store, which return in order and can be waited for with counted
 // vmcnt(N), leaving the younger look-ahead loads in flight.
-#ifndef CVX_EXP_FLAT
 #define CVX_GLOBAL __attribute__((address_space(1)))
-#else
-#define CVX_GLOBAL
-#endif
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4))); // (HIP's uint4 / uint2 classes cannot be copied out of a qualified address space)
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef const CVX_GLOBAL uint8_t *gptr_arena;
@@ -44,21 +40,11 @@ __device__ __forceinline__ uint2 ld2(gptr_arena arena, uint32_t byteOff) { const
 __device__ __forceinline__ uint32_t ld1(gptr_arena arena, uint32_t byteOff) { return *(const CVX_GLOBAL uint32_t *)(arena + byteOff); }
 // Raybuffer tile: wave-uniform tile base + 32-bit byte offset (pixel row y of the lane's column: y * 256 + lane * 4)
 typedef CVX_GLOBAL uint8_t *gptr_tile;
-#ifdef CVX_EXP_LANE_MAJOR /* traffic experiment only (read-back / blit do not know this layout): a lane's pixels contiguous, laneByteOff = lane * colLen * 4 */
-__device__ __forceinline__ void st_pixel(gptr_tile tile, uint32_t laneByteOff, int y, uint32_t argb) { *(CVX_GLOBAL uint32_t *)(tile + ((uint32_t)y * 4u + laneByteOff)) = argb; }
-#else
 __device__ __forceinline__ void st_pixel(gptr_tile tile, uint32_t laneByteOff, int y, uint32_t argb) { *(CVX_GLOBAL uint32_t *)(tile + ((uint32_t)y * (CVX_WAVE * 4u) + laneByteOff)) = argb; }
-#endif
-#ifdef CVX_EXP_NOSTORE /* timing experiment only (wrong pictures): what the pixel stores of the column loop cost */
-#define st_pixel_loop(tile, lane, y, argb) asm volatile("" ::"v"(argb), "v"(y))
-#else
+// (timing builds of rounds 2-4 -- no stores, no colour loads, constant texture index, lane-major tiles, flat addressing, no block-layout hints, no
+// drain at the end of a drawn column -- are archived in tools/patches/exp_timing_switches.patch with their numbers in profiles/r02..r04_experiments.md)
 #define st_pixel_loop st_pixel
-#endif
-#ifdef CVX_EXP_NOCOLORLOAD /* timing experiment only: what the colour loads cost */
-#define ld_color(arena, off) (off)
-#else
 #define ld_color ld1
-#endif
 
 // Byte offset (inside the level's table) of the 32-byte record of LOD column (cx, cz): row-major, cvx_device.h
 __device__ __forceinline__ uint32_t record_offset(int cx, int cz, int rowShift)
@@ -149,14 +135,9 @@ __device__ __forceinline__ f3 f3_lerp(f3 a, f3 b, float t) { return { a.x + (b.x
 
 // Block layout: conditions that hold for (almost) no / (almost) every lane on every kind of input -- exits, near-plane clipping, non-finite or
 // denormal operands, LOD switches, columns with more than two solid runs -- are marked so that the common path is the fall-through one.  The
-// column loop executes ~47 branches per step and is bound by its instruction stream: -1.7 % (32.8 -> 32.2 ms per 512 frames, -DCVX_EXP_NOHINTS to compare).
-#ifndef CVX_EXP_NOHINTS
+// column loop executes ~47 branches per step and is bound by its instruction stream: -1.7 % (32.8 -> 32.2 ms per 512 frames, round 2).
 #define CVX_RARE(x) __builtin_expect(!!(x), 0)
 #define CVX_USUAL(x) __builtin_expect(!!(x), 1)
-#else
-#define CVX_RARE(x) (x)
-#define CVX_USUAL(x) (x)
-#endif
 // boolean algebra on lane masks in clip_world_bounds.  Written with `&&` / `||` on purpose: for these flags (every operand a plain compare result, no side
 // effect to guard) the compiler turns the short-circuit forms into one s_and_b64 / s_or_b64 each -- the same code `&` / `|` on the converted
 // ints give, measured (r03_experiments.md: -0.8 %); what must be avoided between lane masks is `?:`, which became a divergent branch.
@@ -889,9 +870,6 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 								frustumDirMaxWorld = CVX_FLOAT_EPSILON;
 								// perspective-correct colour of pixel y of the run's side, :524-531
 								auto colourOffset = [&](int y) -> uint32_t {
-#ifdef CVX_EXP_NOTEX /* timing experiment only (wrong pictures): what the per-pixel texture arithmetic costs */
-									return worldColumnColorsOff + (uint32_t)(elementColorsIndex + (y & 0)) * 4u;
-#endif
 									float l = ((float)y - boundsX) / (boundsY - boundsX); // unlerp
 									float wux = m_lerp(uvAx, uvBx, l);
 									float wuy = m_lerp(uvAy, uvBy, l);
@@ -1076,15 +1054,16 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			if (draw) {
 				alive = drawColumn(header, queue);
 				if (COUNT) { cnt.E += consumed; }
-#ifndef CVX_EXP_NO_DRAIN
 				// Every vector-memory operation of the drawn column is complete from here on.  Without this the compiler does not know what the pixel loops left in
 				// flight (a colour load whose pixel loop never ran, stores) when the paths of a drawn and a skipped column join below, and drains the queue
 				// there with s_waitcnt vmcnt(0) -- in EVERY step, also a skipped column's, whose only pending loads are the look-ahead record issued ~30
 				// instructions earlier: the one-step look-ahead was being waited for in the step that issued it (rounds 1-3).  With the drain on the drawn
 				// path only (where a colour load, being younger, has waited for the look-ahead anyway), the join knows that nothing but the look-ahead can
 				// be pending and the wait for it moves to its first use, the top of the next step.
-				__builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0), expcnt / lgkmcnt untouched (gfx9 encoding)
+#if !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__) && defined(__HIP_DEVICE_COMPILE__)
+#error "the s_waitcnt immediate below is the gfx9 encoding (vmcnt in bits 3:0 + 15:14, expcnt 6:4, lgkmcnt 11:8); this library is written for gfx950"
 #endif
+				__builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0), expcnt / lgkmcnt untouched (gfx9 encoding)
 			}
 			CVX_BEGIN();
 		}
@@ -1179,11 +1158,7 @@ __global__ __launch_bounds__(CVX_WAVE, CVX_WAVES_PER_SIMD) void render_kernel(co
 		}
 	}
 	const gptr_tile tileOut = (gptr_tile)tile.out;
-#ifdef CVX_EXP_LANE_MAJOR
-	const uint32_t laneByteOff = (uint32_t)(firstLane + vlane) * (uint32_t)S.colLen * 4u;
-#else
 	const uint32_t laneByteOff = (uint32_t)(firstLane + vlane) * 4u;
-#endif
 	uint32_t *seen = lds + vlane - (wordBase << sshift);
 	ProfLane prof;
 #ifdef CVX_PROFILE_SECTIONS

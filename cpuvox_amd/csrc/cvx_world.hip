@@ -10,6 +10,7 @@
 
 #include "cvx_context.h"
 #include "cvx_downsample.h"
+#include "cpuvox_gpu_diag.h"
 
 using cvxi::Fail;
 using cvxi::IsPow2;
@@ -204,6 +205,16 @@ int UploadSourceBlob(cvx_context *ctx, const void *storage, int64_t byteLength, 
 }
 
 // World.DownSample(extraLods) of the validated blob at dSrc (device); see cvx_world_downsample.
+// Exclusive prefix sum of n counts in place, *total = their sum: chunk sums, their offsets, the chunks again (cvx_downsample.h).
+// chunkSums: (n + CVX_SCAN_CHUNK - 1) / CVX_SCAN_CHUNK words of 8 bytes.
+void ExclusiveScan(hipStream_t stream, uint32_t *values, int n, unsigned long long *chunkSums, unsigned long long *total)
+{
+	const unsigned chunks = (unsigned)(((long long)n + CVX_SCAN_CHUNK - 1) / CVX_SCAN_CHUNK);
+	hipLaunchKernelGGL(cvxk::scan_chunk_sums_kernel, dim3(chunks), dim3(CVX_SCAN_THREADS), 0, stream, values, n, chunkSums);
+	hipLaunchKernelGGL(cvxk::scan_chunk_offsets_kernel, dim3(1), dim3(CVX_SCAN_THREADS), 0, stream, chunkSums, (int)chunks, total);
+	hipLaunchKernelGGL(cvxk::scan_apply_kernel, dim3(chunks), dim3(CVX_SCAN_THREADS), 0, stream, values, n, chunkSums);
+}
+
 int DownsampleDevice(cvx_context *ctx, const uint8_t *dSrc, int dimX, int dimY, int dimZ, int lod, int columnCount, int extraLods,
                      void **outStorage, int64_t *outByteLength, int32_t *outColumnCount, int64_t *outVoxelCount, float *outDeviceMs)
 {
@@ -284,12 +295,7 @@ int DownsampleDevice(cvx_context *ctx, const uint8_t *dSrc, int dimX, int dimY, 
 	} else {
 		hipLaunchKernelGGL((cvxk::downsample_kernel<false>), dim3((unsigned)targetColumns), dim3(dsThreads), dsLdsBytes, ctx->stream, P, O);
 	}
-	{ // exclusive scan of the element counts: chunk sums, their offsets, the chunks again (cvx_downsample.h)
-		const unsigned chunks = (unsigned)((targetColumns + CVX_SCAN_CHUNK - 1) / CVX_SCAN_CHUNK);
-		hipLaunchKernelGGL(cvxk::scan_chunk_sums_kernel, dim3(chunks), dim3(CVX_SCAN_THREADS), 0, ctx->stream, dAlloc, (int)targetColumns, dChunkSums);
-		hipLaunchKernelGGL(cvxk::scan_chunk_offsets_kernel, dim3(1), dim3(CVX_SCAN_THREADS), 0, ctx->stream, dChunkSums, (int)chunks, dScalars + 1);
-		hipLaunchKernelGGL(cvxk::scan_apply_kernel, dim3(chunks), dim3(CVX_SCAN_THREADS), 0, ctx->stream, dAlloc, (int)targetColumns, dChunkSums);
-	}
+	ExclusiveScan(ctx->stream, dAlloc, (int)targetColumns, dChunkSums, dScalars + 1); // element counts -> element offsets
 	CVX_DS(hipGetLastError());
 	unsigned long long scalars[3] = { 0, 0, 0 };
 	CVX_DS(hipMemcpyAsync(scalars, dScalars, sizeof scalars, hipMemcpyDeviceToHost, ctx->stream));
@@ -387,6 +393,34 @@ int cvx_world_build_lods(cvx_context *ctx, const void *storage, int64_t byteLeng
 	if (outDeviceMs) { *outDeviceMs = totalMs; }
 	return CVX_OK;
 }
+
+#if defined(CVX_EXPERIMENTS) || defined(CVX_PROFILE_SECTIONS) /* include/cpuvox_gpu_diag.h: not in the product library */
+int cvx_selftest_scan(cvx_context *ctx, int n, uint32_t *values, uint64_t *total)
+{
+	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
+	if (n <= 0 || !values || !total) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "bad arguments"); }
+	CVX_HIP(ctx, hipSetDevice(ctx->device));
+	const size_t chunks = ((size_t)n + CVX_SCAN_CHUNK - 1) / CVX_SCAN_CHUNK;
+	uint8_t *d = nullptr;
+	const size_t valueBytes = ((size_t)n * 4 + 15) & ~(size_t)15;
+	CVX_HIP(ctx, hipMalloc((void **)&d, valueBytes + (chunks + 1) * 8));
+	uint32_t *dValues = reinterpret_cast<uint32_t *>(d);
+	unsigned long long *dChunkSums = reinterpret_cast<unsigned long long *>(d + valueBytes), *dTotal = dChunkSums + chunks;
+	unsigned long long sum = 0;
+	hipError_t e = hipMemcpyAsync(dValues, values, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
+	if (e == hipSuccess) {
+		ExclusiveScan(ctx->stream, dValues, n, dChunkSums, dTotal);
+		e = hipGetLastError();
+	}
+	if (e == hipSuccess) { e = hipMemcpyAsync(values, dValues, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream); }
+	if (e == hipSuccess) { e = hipMemcpyAsync(&sum, dTotal, 8, hipMemcpyDeviceToHost, ctx->stream); }
+	if (e == hipSuccess) { e = hipStreamSynchronize(ctx->stream); }
+	(void)hipFree(d);
+	if (e != hipSuccess) { return Fail(ctx, CVX_ERR_HIP, "scan self-test failed: %s", hipGetErrorString(e)); }
+	*total = sum;
+	return CVX_OK;
+}
+#endif
 
 void cvx_free(void *p)
 {

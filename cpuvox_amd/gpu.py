@@ -36,7 +36,7 @@ EXPORTS = [
     "cvx_image_plan_tile_out", "cvx_image_pack", "cvx_image_exchange", "cvx_image_unpack",
 ]
 # include/cpuvox_gpu_diag.h: only the experiment / profiling builds export these (cpuvox_amd.gpu.use_library(".../libcpuvox_gpu_exp.so"))
-DIAG_EXPORTS = ["cvx_selftest_math", "cvx_debug_occupancy", "cvx_debug_section_cycles", "cvx_debug_section_histogram"]
+DIAG_EXPORTS = ["cvx_selftest_math", "cvx_selftest_scan", "cvx_debug_occupancy", "cvx_debug_section_cycles", "cvx_debug_section_histogram"]
 
 
 class Counters(C.Structure):
@@ -135,6 +135,7 @@ def _bind(path: str) -> C.CDLL:
             L.cvx_debug_section_histogram.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_int]
             L.cvx_debug_occupancy.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int)]
             L.cvx_selftest_math.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+            L.cvx_selftest_scan.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_uint64)]
         L.cvx_world_downsample.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_float)]
         L.cvx_world_build_lods.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -406,6 +407,13 @@ class Context:
         out = np.empty_like(a)
         self._check(self._diag("cvx_selftest_math")(self._h, op, a.size, a.ctypes.data, b.ctypes.data, out.ctypes.data))
         return out
+
+    def selftest_scan(self, values: np.ndarray):
+        """Diagnostics build only: (exclusive prefix sums modulo 2^32, 64-bit total) of uint32 values by the device scan of cvx_world_downsample."""
+        v = np.ascontiguousarray(values, dtype=np.uint32).copy()
+        total = C.c_uint64()
+        self._check(self._diag("cvx_selftest_scan")(self._h, v.size, v.ctypes.data, C.byref(total)))
+        return v, int(total.value)
 
 
 class NativeShardPlan:

@@ -28,6 +28,10 @@ int cvx_debug_section_histogram(cvx_context *ctx, uint64_t out[128], int reset);
  * 4 floor, 5 ceil, 6 round-half-even, 7 (int)a with the x86 rule. */
 int cvx_selftest_math(cvx_context *ctx, int op, int n, const float *a, const float *b, float *out);
 
+/* The device prefix sum behind cvx_world_downsample (three launches, cvx_downsample.h) on a caller's array: values[0 .. n) are
+ * replaced by their exclusive prefix sums (modulo 2^32), *total receives the 64-bit sum.  For tests of the tail / multi-chunk paths. */
+int cvx_selftest_scan(cvx_context *ctx, int n, uint32_t *values, uint64_t *total);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,11 +37,12 @@ def contexts():
 
 @pytest.fixture
 def exp_library(monkeypatch):
-    """The experiment build (make gpu-exp, -DCVX_EXPERIMENTS): the only build that reads the diagnostic CVX_* environment switches
-    and contains the state-machine kernel.  The product library reads no environment (tests/test_abi.py)."""
+    """The experiment build (make gpu-exp, -DCVX_EXPERIMENTS): the only build that reads the diagnostic CVX_* environment switches and exports the
+    diagnostics of include/cpuvox_gpu_diag.h (the arithmetic self-test among them).  The product library reads no environment (tests/test_abi.py).
+    `make all` / __graft_entry__.build() always build it next to the product library, from the same sources with the same HIPFLAGS, so a missing
+    file is a broken build, not a reason to skip: the shipped kernels' arithmetic contract is pinned through this build."""
     path = os.path.join(os.path.dirname(gpu.lib_path()), "libcpuvox_gpu_exp.so")
-    if not os.path.exists(path):
-        pytest.skip("libcpuvox_gpu_exp.so not built (make -C cpuvox_amd/csrc gpu-exp)")
+    assert os.path.exists(path), "libcpuvox_gpu_exp.so not built: run `make -C cpuvox_amd/csrc all` (or __graft_entry__.build())"
     gpu.use_library(path)
     yield monkeypatch
     gpu.use_library(None)
@@ -388,6 +389,24 @@ def _float_soup(rng, n):
                        dtype=np.float32)
     x[k:k + special.size] = special
     return x
+
+
+def test_device_scan_tails_and_many_chunks(diag_context):
+    """the three-launch prefix sum of cvx_world_downsample (cvx_downsample.h) against numpy on lengths the power-of-two worlds of the
+    other tests never produce: a ragged last chunk (`first + i < n`, `at < n`), a single short chunk, exactly one chunk, and more than 256 chunks
+    of 4096 (the carry loop of scan_chunk_offsets_kernel runs more than once: a 4096^2 world's LOD 1 has 1024)."""
+    ctx = diag_context
+    rng = np.random.default_rng(99)
+    for n in (1, 5, 4095, 4096, 4097, 6800, 256 * 4096, 256 * 4096 + 17, 3_000_001):
+        values = rng.integers(0, 70, size=n, dtype=np.uint32)
+        got, total = ctx.selftest_scan(values)
+        want = np.concatenate(([0], np.cumsum(values[:-1], dtype=np.uint64))).astype(np.uint64)
+        assert total == int(values.sum(dtype=np.uint64)), n
+        assert np.array_equal(got, (want & 0xFFFFFFFF).astype(np.uint32)), n
+    # sums beyond 2^32: the total is exact in 64 bits (callers refuse > 2^31 elements before they use the 32-bit offsets)
+    big = np.full(70_000, 0xFFFF_0000, dtype=np.uint32)
+    got, total = ctx.selftest_scan(big)
+    assert total == 70_000 * 0xFFFF_0000
 
 
 def test_short_division_is_ieee_division(diag_context):
