@@ -181,31 +181,13 @@ def main():
     # payload every xGMI link would carry per step, printed before anything is allocated
     predicted = None
     if args.frames == "auto":
-        budget = args.hbm_budget_gb * 1e9
-        choice = None
-        for cand in (512, 256, 128, 64, 32, 16, 8):
-            if N > 1:
-                from cpuvox_amd import dist as cdist_
-
-                plan0 = cdist_.ShardPlan([frame_for(i) for i in range(N * cand)], W, H, rank, N)
-                area = 2.0 * (plan0.send_total + plan0.disp_total) * 256.0
-                per_link = plan0.send_total * 256.0 / max(1, N - 1)
-            else:
-                area = cand * 4.0 * (H * (W + 2 * H) + W * (2 * W + H))  # RenderManager.cs:35-36 capacities per raybuffer pair
-                per_link = 0.0
-            choice = (cand, area, per_link)
-            if area <= budget:
-                break
-        else:  #  not even 8 frames per GPU fit: go on with 8 -- the smallest batch the bench runs -- and say so
-            if rank == 0:
-                print(f"bench.py: WARNING --frames auto: no candidate fits --hbm-budget-gb {args.hbm_budget_gb:g} ({choice[1] / 1e9:.2f} GB of areas per GPU "
-                      f"at {choice[0]} frames); running {choice[0]} frames per GPU OVER the budget", file=sys.stderr, flush=True)
-        args.frames = choice[0]
-        predicted = {"frames_per_gpu": choice[0], "area_bytes_per_gpu": int(choice[1]), "hbm_budget_bytes": int(budget), "fits_budget": bool(choice[1] <= budget), "payload_bytes_per_link_per_step": int(choice[2]),
-                     "link_ms_at_153_GBps": round(choice[2] / 153e9 * 1e3, 3)}
+        predicted = predict_frames_auto(frame_for, W, H, rank, N, args.hbm_budget_gb * 1e9)
+        args.frames = predicted["frames_per_gpu"]
         if rank == 0:
-            print(f"bench.py: --frames auto -> {choice[0]} per GPU ({choice[1] / 1e9:.2f} GB of areas per GPU against a budget of {budget / 1e9:.1f} GB; "
-                  f"{choice[2] / 1e6:.1f} MB per peer and step = {choice[2] / 153e9 * 1e3:.2f} ms on one 153 GB/s xGMI link)", file=sys.stderr, flush=True)
+            if not predicted["fits_budget"]:  #  not even the smallest batch fits: go on with it and say so
+                print(f"bench.py: WARNING --frames auto: no candidate fits --hbm-budget-gb {args.hbm_budget_gb:g}; running {args.frames} frames per GPU OVER the budget", file=sys.stderr, flush=True)
+            print(f"bench.py: --frames auto -> {args.frames} per GPU ({predicted['area_bytes_per_gpu'] / 1e9:.2f} GB of areas per GPU against a budget of {args.hbm_budget_gb:.1f} GB; "
+                  f"{predicted['payload_bytes_per_link_per_step'] / 1e6:.1f} MB per peer and step = {predicted['link_ms_at_153_GBps']:.2f} ms on one 153 GB/s xGMI link)", file=sys.stderr, flush=True)
     F = args.frames
     G = N * F  # frames per step, whole job
 
@@ -663,6 +645,28 @@ def main():
         dist.destroy_process_group()
     if parity_failed:
         raise SystemExit("bench.py: the GPU raybuffers of the timed frames differ from the CPU oracle")
+
+
+def predict_frames_auto(frame_for, W, H, rank, N, budget_bytes, candidates=(512, 256, 128, 64, 32, 16, 8)):
+    """--frames auto: the largest F whose raybuffer areas fit the stated HBM budget -- one GPU: F raybuffer pairs; N > 1: the
+    per-destination send sections + the display area, two parities each (exact sizes from the shard plan of step 0) -- and the payload every xGMI
+    link would carry per step, all BEFORE anything is allocated.  Host arithmetic only (tests/test_dist.py runs it for the 8-rank 4K shapes)."""
+    choice = None
+    for cand in candidates:
+        if N > 1:
+            from cpuvox_amd import dist as cdist_
+
+            plan0 = cdist_.ShardPlan([frame_for(i) for i in range(N * cand)], W, H, rank, N)
+            area = 2.0 * (plan0.send_total + plan0.disp_total) * 256.0
+            per_link = plan0.send_total * 256.0 / max(1, N - 1)
+        else:
+            area = cand * 4.0 * (H * (W + 2 * H) + W * (2 * W + H))  # RenderManager.cs:35-36 capacities per raybuffer pair
+            per_link = 0.0
+        choice = (cand, area, per_link)
+        if area <= budget_bytes:
+            break
+    return {"frames_per_gpu": choice[0], "area_bytes_per_gpu": int(choice[1]), "hbm_budget_bytes": int(budget_bytes), "fits_budget": bool(choice[1] <= budget_bytes),
+            "payload_bytes_per_link_per_step": int(choice[2]), "link_ms_at_153_GBps": round(choice[2] / 153e9 * 1e3, 3)}
 
 
 def read_counter_summary(path, warmup, steps):

@@ -275,17 +275,7 @@ class Context:
 
     def pack_batch(self, frames):
         """Marshal frames once; returns an opaque object for draw_packed (keeps bench loops free of Python overhead)."""
-        n = len(frames)
-        segs = (SegmentData * (4 * n))()
-        cams = (CameraData * n)()
-        vps = (C.c_float * (2 * n))()
-        for i, f in enumerate(frames):
-            for s in range(4):
-                segs[4 * i + s] = f.segments[s]
-            cams[i] = f.camera
-            vps[2 * i] = f.vanishingPointScreenSpace[0]
-            vps[2 * i + 1] = f.vanishingPointScreenSpace[1]
-        return (n, segs, cams, vps)
+        return pack_frames(frames)
 
     def draw_packed(self, packed, first_buffer_index: int = 0, flags: int = DRAW_SYNC) -> None:
         n, segs, cams, vps = packed
@@ -414,6 +404,22 @@ class Context:
         total = C.c_uint64()
         self._check(self._diag("cvx_selftest_scan")(self._h, v.size, v.ctypes.data, C.byref(total)))
         return v, int(total.value)
+
+
+def pack_frames(frames):
+    """(n, SegmentData[4 n], CameraData[n], float[2 n]) of a list of host frames: the argument arrays of cvx_draw_segments_batch /
+    cvx_shard_plan_create.  Needs no context and no GPU."""
+    n = len(frames)
+    segs = (SegmentData * (4 * n))()
+    cams = (CameraData * n)()
+    vps = (C.c_float * (2 * n))()
+    for i, f in enumerate(frames):
+        for s in range(4):
+            segs[4 * i + s] = f.segments[s]
+        cams[i] = f.camera
+        vps[2 * i] = f.vanishingPointScreenSpace[0]
+        vps[2 * i + 1] = f.vanishingPointScreenSpace[1]
+    return (n, segs, cams, vps)
 
 
 class NativeShardPlan:

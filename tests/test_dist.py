@@ -287,3 +287,64 @@ def test_exchange_on_real_rccl_two_gpus(gather):
     results.sort()
     assert all(ok for _, ok, _ in results), results
     assert results[0][2] > 0 and results[1][2] > 0
+
+
+@pytest.mark.parametrize("name, dim, lod_error", [("config4", 2048, 1.0), ("config5", 4096, 4.0)])
+def test_eight_rank_plan_of_the_4k_shapes_fits_its_hbm_budget(name, dim, lod_error):
+    """VERDICT r4 item 7 (RenderManager.cs:35-36): a pinned dry run of what the first real 8-GPU run of BASELINE configs 4 / 5
+    (3840x2160, 2048^3 / 4096^3) will allocate and put on the wire -- `bench.py --gpus 8 --frames auto` as host arithmetic, no GPU, no world
+    (a frame only needs the world's dimensions).  Asserts, for every rank: the chosen frame count's send + display areas (two parities) fit the
+    stated budget (default 96 GB of the 288 GB) AND the device; what leaves a rank is what its peers expect; every frame's rows are displayed
+    exactly once; the per-link payload bench.py prints is the plan's; the native plan the exchange uses (cvx_shard_plan_*) agrees."""
+    import importlib.util
+
+    from cpuvox_amd import gpu, host
+
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    W, H, N = 3840, 2160, 8
+    dims = (dim, dim, dim)
+    lods, far = host.setup_lods(host.camera_pose((0, 0, 0), (0, 0, 0), W, H), dim, W, H, lod_error)
+    cache = {}
+
+    def frame_for(g):  # bench.py's frame_for: global frame g -> benchmark pose (g * stride) % POSES
+        i = (g * bench.POSE_STRIDE) % bench.POSES
+        if i not in cache:
+            pos, eul = host.sample_benchmark_path(i / bench.POSES * host.BENCHMARK_PATH_LENGTH, dims)
+            cache[i] = host.setup_frame(host.camera_pose(pos, eul, W, H), lods, far, W, H, dims[1])
+        return cache[i]
+
+    budget = 96e9
+    # the candidates a CPU test can afford (plans are Python loops over every tile): the shape of the answer, not the largest batch
+    predictions = [bench.predict_frames_auto(frame_for, W, H, r, N, budget, candidates=(32, 8)) for r in range(N)]
+    F = predictions[0]["frames_per_gpu"]
+    assert all(p["frames_per_gpu"] == F and p["fits_budget"] for p in predictions), predictions
+    frames = [frame_for(i) for i in range(N * F)]
+    plans = [cdist.ShardPlan(frames, W, H, r, N) for r in range(N)]
+    rows_per_frame_total = 0
+    for fr in frames:
+        rc = [s.RayCount for s in fr.segments]
+        ranges = cdist.segment_pixel_ranges(fr.vanishingPointScreenSpace, W, H)
+        rows_per_frame_total += sum(ranges[seg][1] - ranges[seg][0] + 1 for _, _, seg in cdist.frame_tiles(rc))
+    assert sum(p.disp_total for p in plans) == rows_per_frame_total  # every writable row of every frame lands on exactly one display rank
+    for r, (p, pred) in enumerate(zip(plans, predictions)):
+        area = 2 * (p.send_total + p.disp_total) * 256
+        assert pred["area_bytes_per_gpu"] == area <= budget < 288e9
+        assert pred["payload_bytes_per_link_per_step"] == p.send_total * 256 // (N - 1)
+        for q in range(N):  # what r sends to q is what q keeps for r
+            assert p.send_start[q + 1] - p.send_start[q] == (plans[q].disp_start[r + 1] - plans[q].disp_start[r] if q != r else 0)
+    # scaled to the 512 frames per GPU the bench would pick first: areas and per-link payload are linear in the frame count (poses repeat every 1000)
+    worst = max(2 * (p.send_total + p.disp_total) * 256 for p in plans) * (512 / F)
+    link = max(p.send_total * 256 / (N - 1) for p in plans) * (512 / F)
+    assert worst < 288e9 * 0.9, f"{name}: 512 frames per GPU would need {worst / 1e9:.1f} GB of areas"
+    print(f"{name}: {F} frames/GPU -> {predictions[0]['area_bytes_per_gpu'] / 1e9:.2f} GB areas, {predictions[0]['payload_bytes_per_link_per_step'] / 1e6:.1f} MB per link and step; "
+          f"at 512 frames/GPU ~{worst / 1e9:.1f} GB areas, ~{link / 1e6:.0f} MB = {link / 153e9 * 1e3:.1f} ms per link and step")
+    # the plan the C-ABI exchange uses is the same plan (host arithmetic of libcpuvox_gpu, no device needed)
+    ctx_free_pack = gpu.pack_frames(frames) if hasattr(gpu, "pack_frames") else None
+    if ctx_free_pack is not None:
+        for r in (0, N - 1):
+            native = gpu.NativeShardPlan(ctx_free_pack, W, H, r, N)
+            assert native.tile_count == plans[r].tile_count and list(native.send_start) == list(plans[r].send_start) and list(native.disp_start) == list(plans[r].disp_start)
