@@ -19,9 +19,29 @@ namespace cvxk {
 
 #define CVX_DS_BUCKETS 256 /* target-Y buckets held in LDS per pass over the sources (6 KB); taller occupied spans take several passes */
 
+// One solid voxel of a level >= 1 as the NEXT level needs it (round 5: the LOD chain reads LOD 0 once).  World.DownSample always starts from LOD 0
+// (UnityManager.cs:328-331), and a colour of level j is (sum of the LOD-0 voxels under the bucket) / (their number) per channel in integers -- which
+// cannot be derived from the rounded colours of level j - 1, but CAN from that level's sums: sums and counts of the eight children add up.  The alpha of
+// a bucket is that of the voxel the reference inserts FIRST (RLEColumnBuilder keeps the first of equal Ys, WordBuilder.cs:199-214, in the insertion
+// order of World.cs:85-94,101-127: source columns ix-major, runs top-down, voxels of a run bottom-up), i.e. of the lexicographically first LOD-0
+// column (x, z) that has a voxel in the bucket, its topmost run reaching into the bucket, that run's lowest voxel inside the bucket.  Per bucket:
+//   key   = x << 16 | z of that LOD-0 column (all candidates of a target column share their high bits, so the order of keys is the insertion order),
+//   alpha = the alpha described above,
+//   cont  = that run goes on below the bucket.
+// For a parent bucket (children: upper and lower half, four columns): the winner is the smallest key among the present children; if the winner has a
+// voxel in the upper half and cont(upper), its first voxel lies in the lower half (same run: alpha(lower), cont(lower)), else in the upper half
+// (alpha(upper), no continuation); a winner present in the lower half only: alpha(lower), cont(lower).  (A column that has voxels in a half IS that
+// half's winner whenever it is the parent's: a smaller column with a voxel there would have been the parent's.)
+struct SumVoxel {
+	uint32_t r, g, b, n; // channel sums and number of the LOD-0 voxels under the bucket
+	uint32_t key;        // x << 16 | z of the LOD-0 column whose voxel the reference inserts first
+	uint32_t af;         // its alpha | cont << 8
+};
+
 struct DownsampleParams {
 	const uint32_t *srcHeaders;  // 12-byte RLEColumn headers as 3 words each
 	const uint32_t *srcElements; // element / colour pool
+	const SumVoxel *srcSums;     // SUMS_IN: sums of the source level, indexed like srcElements (only the slots of colours are used)
 	int srcLod, extraLods;
 	int dimY;
 	int srcMulX;        // dimZ >> srcLod
@@ -35,6 +55,7 @@ struct DownsampleOut {
 	uint32_t *runCounts; // pass 1 out / pass 2 in
 	uint32_t *headers;   // pass 2: 3 words per target column (table zero-initialised by the host)
 	uint32_t *elements;  // pass 2
+	SumVoxel *sums;      // pass 2, SUMS_OUT: sums of the level being written, indexed like `elements`
 	unsigned long long *voxelCount;
 	int *error; // 1: a column needs more than 65535 runs (World.cs:193-195)
 };
@@ -267,9 +288,13 @@ __global__ __launch_bounds__(256) void downsample_kernel(DownsampleParams P, Dow
 // encoding of RLEColumnBuilder.ToFinalColumn (WordBuilder.cs:181-268) as a scalar state machine.  Same two passes around the
 // same scan, byte-identical output (tests: device blob == host blob).
 // ---------------------------------------------------------------------------------------------------------------------
-template <bool WRITE, int E>
+// SUMS_IN (E == 1 only): the source is a level >= 1 with its SumVoxel table instead of LOD 0 with its colours; SUMS_OUT: the write pass also stores the
+// SumVoxel of every bucket for the next level (cvx_world_build_lods: LOD 0 is read once, every further level reads the one before it).
+template <bool WRITE, int E, bool SUMS_IN = false, bool SUMS_OUT = false>
 __global__ __launch_bounds__(64) void downsample_thread_kernel(DownsampleParams P, DownsampleOut O)
 {
+	static_assert(!SUMS_IN || E == 1, "a level is built from the sums of the level right below it");
+	static_assert(!SUMS_OUT || E == 1, "sums are emitted by the 2 x 2 kernel only");
 	constexpr int steps = 1 << E, S = steps * steps;
 	const int k = blockIdx.x * blockDim.x + threadIdx.x;
 	if (k >= P.targetColumns) {
@@ -387,8 +412,12 @@ __global__ __launch_bounds__(64) void downsample_thread_kernel(DownsampleParams 
 		yPrev = y;
 		const int bLo = y << E, bHi = bLo + steps - 1; // source Ys of this bucket
 		uint32_t sumR = 0u, sumG = 0u, sumB = 0u, n = 0u, firstAlpha = 0u;
+		uint32_t firstKey = 0xFFFFFFFFu, firstCont = 0u; // SUMS_IN / SUMS_OUT: see SumVoxel
 #pragma unroll
 		for (int s = 0; s < S; s++) {
+			// SUMS_IN: what this source column holds in the upper (Y = 2 y + 1) and the lower (Y = 2 y) half of the bucket
+			bool hasU = false;
+			uint32_t keyU = 0xFFFFFFFFu, keyL = 0xFFFFFFFFu, afU = 0u, afL = 0u;
 			while (curLen[s] > 0) {
 				const int lo = curLo[s], hi = lo + curLen[s] - 1;
 				if (hi < bLo) {
@@ -398,12 +427,33 @@ __global__ __launch_bounds__(64) void downsample_thread_kernel(DownsampleParams 
 				const int yFrom = lo > bLo ? lo : bLo, yTo = hi < bHi ? hi : bHi;
 				for (int Y = yFrom; Y <= yTo; Y++) {
 					const int i = Y - lo;
-					const uint32_t c = colourPool[curColour[s] + (uint32_t)(colourIndexOfRun[s] + curLen[s] - i - 1)]; // bytes a, r, g, b
-					if (n == 0u) { firstAlpha = c & 0xFFu; }
-					sumR += (c >> 8) & 0xFFu;
-					sumG += (c >> 16) & 0xFFu;
-					sumB += c >> 24;
-					n++;
+					const uint32_t at = curColour[s] + (uint32_t)(colourIndexOfRun[s] + curLen[s] - i - 1);
+					if (SUMS_IN) {
+						if (WRITE) { // (the counting pass only needs the occupancy)
+							const SumVoxel v = P.srcSums[at];
+							sumR += v.r;
+							sumG += v.g;
+							sumB += v.b;
+							n += v.n;
+							if (Y & 1) { hasU = true; keyU = v.key; afU = v.af; } else { keyL = v.key; afL = v.af; }
+						} else {
+							n++;
+						}
+					} else {
+						const uint32_t c = colourPool[at]; // bytes a, r, g, b
+						if (n == 0u) {
+							firstAlpha = c & 0xFFu;
+							if (SUMS_OUT) { // this source column is the first in insertion order with a voxel here; `lo < bLo`: its run goes on below the bucket
+								const int x = xStart + (s / steps) * stepSize, z = zStart + (s % steps) * stepSize;
+								firstKey = ((uint32_t)x << 16) | (uint32_t)z;
+								firstCont = lo < bLo ? 1u : 0u;
+							}
+						}
+						sumR += (c >> 8) & 0xFFu;
+						sumG += (c >> 16) & 0xFFu;
+						sumB += c >> 24;
+						n++;
+					}
 				}
 				if (lo >= bLo) {
 					curLen[s] = 0; // consumed: the next run of this source may reach into the same bucket
@@ -415,6 +465,23 @@ __global__ __launch_bounds__(64) void downsample_thread_kernel(DownsampleParams 
 				colourIndexOfRun[s] += curLen[s] - (bLo - lo);
 				curLen[s] = bLo - lo;
 				break;
+			}
+			if (SUMS_IN && WRITE) { // the parent rule of SumVoxel, applied to this source's winner if it beats the sources before it
+				const uint32_t keyS = keyU < keyL ? keyU : keyL; // (0xFFFFFFFF = absent)
+				if (keyS < firstKey) {
+					firstKey = keyS;
+					const bool inU = hasU && keyU == keyS;
+					if (inU && ((afU >> 8) & 1u)) { // its topmost run crosses into the lower half: the first voxel is the lower half's
+						firstAlpha = afL & 0xFFu;
+						firstCont = (afL >> 8) & 1u;
+					} else if (inU) {
+						firstAlpha = afU & 0xFFu;
+						firstCont = 0u;
+					} else {
+						firstAlpha = afL & 0xFFu;
+						firstCont = (afL >> 8) & 1u;
+					}
+				}
 			}
 		}
 		// (n > 0: the bucket was chosen because a run reaches into it)
@@ -430,6 +497,9 @@ __global__ __launch_bounds__(64) void downsample_thread_kernel(DownsampleParams 
 		runLen++;
 		if (WRITE) {
 			O.elements[colourBase + (uint32_t)solid] = firstAlpha | ((sumR / n) << 8) | ((sumG / n) << 16) | ((sumB / n) << 24);
+			if (SUMS_OUT) {
+				O.sums[colourBase + (uint32_t)solid] = SumVoxel{ sumR, sumG, sumB, n, firstKey, firstAlpha | (firstCont << 8) };
+			}
 		}
 		solid++;
 	}

@@ -343,6 +343,146 @@ int DownsampleDevice(cvx_context *ctx, const uint8_t *dSrc, int dimX, int dimY, 
 	return CVX_OK;
 }
 
+// The whole LOD chain in one go, LOD 0 read ONCE (round 5): level 1 from LOD 0's colours, every further level from the level
+// before it through its table of per-voxel sums (cvxk::SumVoxel: channel sums, count, and the key / alpha / continuation that reproduce the
+// reference's "first inserted voxel keeps its alpha").  Same kernels, same two passes around the same scan per level as DownsampleDevice, but no host
+// round trip between them: the element pools are sized by a bound instead of by the scanned total -- a target column needs at most the elements of its
+// four sources + 2 (its solid runs are unions of theirs, one more air run, two guards; halving Y never adds runs), so level j has at most
+// elements(LOD 0) + 2 (columns(1) + ... + columns(j)) < elements(LOD 0) + columns(LOD 0) of them -- and every error is looked at once, at the end.
+// Levels above `kMaxChainLevel` (channel sums of 2^24 voxels x 255 no longer fit 32 bits) are left to DownsampleDevice.
+constexpr int kMaxChainLevel = 7;
+
+int BuildLodChainDevice(cvx_context *ctx, const uint8_t *dSrc, int64_t byteLength, int dimX, int dimY, int dimZ, int columnCount, int levelCount,
+                        void **outStorage, int64_t *outByteLength, int32_t *outColumnCount, float *outDeviceMs)
+{
+	struct Level {
+		int64_t targetColumns = 0, allocatedColumns = 0;
+		uint32_t *dTables = nullptr, *dHeaders = nullptr, *dElements = nullptr;
+		unsigned long long *dChunkSums = nullptr;
+	};
+	std::vector<Level> L((size_t)levelCount + 1);
+	cvxk::SumVoxel *dSums[2] = { nullptr, nullptr };
+	unsigned long long *dScalars = nullptr; // per level: [0] voxel count, [1] element total, [2] error flag
+	hipEvent_t evBegin = nullptr, evEnd = nullptr;
+	std::vector<void *> host((size_t)levelCount, nullptr);
+	auto release = [&]() {
+		for (Level &l : L) {
+			if (l.dTables) { (void)hipFree(l.dTables); }
+			if (l.dHeaders) { (void)hipFree(l.dHeaders); }
+			if (l.dElements) { (void)hipFree(l.dElements); }
+		}
+		for (cvxk::SumVoxel *p : dSums) { if (p) { (void)hipFree(p); } }
+		if (dScalars) { (void)hipFree(dScalars); }
+		if (evBegin) { (void)hipEventDestroy(evBegin); }
+		if (evEnd) { (void)hipEventDestroy(evEnd); }
+	};
+	auto fail = [&](int rc) {
+		release();
+		for (void *p : host) { std::free(p); }
+		return rc;
+	};
+#define CVX_CH(call)                                                                                                                          \
+	do {                                                                                                                                      \
+		hipError_t e_ = (call);                                                                                                               \
+		if (e_ != hipSuccess) { return fail(Fail(ctx, CVX_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__)); } \
+	} while (0)
+	const int64_t usedColumns0 = (int64_t)dimX * dimZ;
+	const int64_t elements0 = (byteLength - (int64_t)columnCount * 12) / 4;
+	const int64_t elementBound = elements0 + usedColumns0; // (see above; >= 1)
+	if (elementBound > 0x7FFFFFFFll) { return Fail(ctx, CVX_ERR_CAPACITY, "Only supports up to 2^31 elements (World.cs:355-357)"); }
+	for (int j = 1; j <= levelCount; j++) {
+		Level &l = L[(size_t)j];
+		if ((dimX >> j) < 1 || (dimY >> j) < 1 || (dimZ >> j) < 1) { return fail(Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "LOD %d out of range for these dimensions", j)); }
+		l.targetColumns = (int64_t)(dimX >> j) * (dimZ >> j);
+		l.allocatedColumns = ((int64_t)dimX * dimZ) / ((int64_t)(j + 1) * (j + 1)); // World.ColumnCount, World.cs:17
+		if (l.allocatedColumns > 0x7FFFFFFF || l.allocatedColumns < l.targetColumns) { return fail(Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "target LOD has an unsupported column count")); }
+		const size_t scanChunks = (size_t)((l.targetColumns + CVX_SCAN_CHUNK - 1) / CVX_SCAN_CHUNK);
+		const size_t tableWords = ((size_t)l.targetColumns * 2 + 1) & ~(size_t)1;
+		CVX_CH(hipMalloc((void **)&l.dTables, tableWords * sizeof(uint32_t) + (scanChunks + 1) * sizeof(unsigned long long)));
+		l.dChunkSums = reinterpret_cast<unsigned long long *>(l.dTables + tableWords);
+		CVX_CH(hipMalloc((void **)&l.dHeaders, (size_t)l.allocatedColumns * 12));
+		CVX_CH(hipMalloc((void **)&l.dElements, (size_t)elementBound * sizeof(uint32_t)));
+		CVX_CH(hipMemsetAsync(l.dHeaders, 0, (size_t)l.allocatedColumns * 12, ctx->stream));
+	}
+	for (int i = 0; i < 2 && i < levelCount - 1; i++) { CVX_CH(hipMalloc((void **)&dSums[i], (size_t)elementBound * sizeof(cvxk::SumVoxel))); }
+	CVX_CH(hipMalloc((void **)&dScalars, (size_t)levelCount * 3 * sizeof(unsigned long long)));
+	CVX_CH(hipMemsetAsync(dScalars, 0, (size_t)levelCount * 3 * sizeof(unsigned long long), ctx->stream));
+	CVX_CH(hipEventCreate(&evBegin));
+	CVX_CH(hipEventCreate(&evEnd));
+
+	CVX_CH(hipEventRecord(evBegin, ctx->stream));
+	for (int j = 1; j <= levelCount; j++) {
+		Level &l = L[(size_t)j];
+		const bool fromLod0 = j == 1, emitSums = j < levelCount;
+		cvxk::DownsampleParams P{};
+		P.srcHeaders = fromLod0 ? reinterpret_cast<const uint32_t *>(dSrc) : L[(size_t)j - 1].dHeaders;
+		P.srcElements = fromLod0 ? reinterpret_cast<const uint32_t *>(dSrc + (size_t)columnCount * 12) : L[(size_t)j - 1].dElements;
+		P.srcSums = fromLod0 ? nullptr : dSums[(j - 1) & 1];
+		P.srcLod = j - 1;
+		P.extraLods = 1;
+		P.dimY = dimY;
+		P.srcMulX = dimZ >> (j - 1);
+		P.targetColumnsZ = dimZ >> j;
+		P.targetColumns = (int)l.targetColumns;
+		P.chunkBuckets = 0;
+		cvxk::DownsampleOut O{};
+		O.alloc = l.dTables;
+		O.runCounts = l.dTables + l.targetColumns;
+		O.headers = l.dHeaders;
+		O.elements = l.dElements;
+		O.sums = emitSums ? dSums[j & 1] : nullptr;
+		unsigned long long *scalars = dScalars + (size_t)(j - 1) * 3;
+		O.voxelCount = scalars;
+		O.error = reinterpret_cast<int *>(scalars + 2);
+		const dim3 grid((unsigned)((l.targetColumns + 63) / 64)), block(64);
+		if (fromLod0) {
+			hipLaunchKernelGGL((cvxk::downsample_thread_kernel<false, 1, false, false>), grid, block, 0, ctx->stream, P, O);
+		} else {
+			hipLaunchKernelGGL((cvxk::downsample_thread_kernel<false, 1, true, false>), grid, block, 0, ctx->stream, P, O);
+		}
+		ExclusiveScan(ctx->stream, l.dTables, (int)l.targetColumns, l.dChunkSums, scalars + 1); // element counts -> element offsets
+		if (fromLod0) {
+			if (emitSums) {
+				hipLaunchKernelGGL((cvxk::downsample_thread_kernel<true, 1, false, true>), grid, block, 0, ctx->stream, P, O);
+			} else {
+				hipLaunchKernelGGL((cvxk::downsample_thread_kernel<true, 1, false, false>), grid, block, 0, ctx->stream, P, O);
+			}
+		} else if (emitSums) {
+			hipLaunchKernelGGL((cvxk::downsample_thread_kernel<true, 1, true, true>), grid, block, 0, ctx->stream, P, O);
+		} else {
+			hipLaunchKernelGGL((cvxk::downsample_thread_kernel<true, 1, true, false>), grid, block, 0, ctx->stream, P, O);
+		}
+		CVX_CH(hipGetLastError());
+	}
+	CVX_CH(hipEventRecord(evEnd, ctx->stream));
+	std::vector<unsigned long long> scalars((size_t)levelCount * 3, 0ull);
+	CVX_CH(hipMemcpyAsync(scalars.data(), dScalars, scalars.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+	CVX_CH(hipStreamSynchronize(ctx->stream));
+	for (int j = 1; j <= levelCount; j++) {
+		if ((int)scalars[(size_t)(j - 1) * 3 + 2] != 0) { return fail(Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "a downsampled column needs more than 65535 runs (World.cs:193-195)")); }
+		if (scalars[(size_t)(j - 1) * 3 + 1] > (unsigned long long)elementBound) { return fail(Fail(ctx, CVX_ERR_CAPACITY, "LOD %d: element total beyond its bound (internal error)", j)); }
+	}
+	for (int j = 1; j <= levelCount; j++) {
+		Level &l = L[(size_t)j];
+		const size_t headerBytes = (size_t)l.allocatedColumns * 12, elementTotal = (size_t)scalars[(size_t)(j - 1) * 3 + 1];
+		const size_t outBytes = headerBytes + elementTotal * 4;
+		host[(size_t)j - 1] = std::malloc(outBytes > 0 ? outBytes : 1);
+		if (!host[(size_t)j - 1]) { return fail(Fail(ctx, CVX_ERR_HIP, "out of host memory")); }
+		CVX_CH(hipMemcpyAsync(host[(size_t)j - 1], l.dHeaders, headerBytes, hipMemcpyDeviceToHost, ctx->stream));
+		if (elementTotal > 0) { CVX_CH(hipMemcpyAsync(static_cast<uint8_t *>(host[(size_t)j - 1]) + headerBytes, l.dElements, elementTotal * 4, hipMemcpyDeviceToHost, ctx->stream)); }
+		outByteLength[j - 1] = (int64_t)outBytes;
+		outColumnCount[j - 1] = (int32_t)l.allocatedColumns;
+	}
+	CVX_CH(hipStreamSynchronize(ctx->stream));
+	float ms = 0.0f;
+	CVX_CH(hipEventElapsedTime(&ms, evBegin, evEnd));
+#undef CVX_CH
+	release();
+	for (int j = 0; j < levelCount; j++) { outStorage[j] = host[(size_t)j]; }
+	if (outDeviceMs) { *outDeviceMs = ms; }
+	return CVX_OK;
+}
+
 } // namespace
 
 /* World.DownSample(extraLods), World.cs:45-127, on the device (cvx_downsample.h). */
@@ -376,8 +516,11 @@ int cvx_world_build_lods(cvx_context *ctx, const void *storage, int64_t byteLeng
 	uint8_t *dSrc = nullptr;
 	int rc = UploadSourceBlob(ctx, storage, byteLength, dimX, dimY, dimZ, 0, columnCount, &dSrc);
 	if (rc != CVX_OK) { return rc; }
+	// levels 1 .. min(levelCount, 7) as one chain that reads LOD 0 once; anything above from LOD 0 directly
 	float totalMs = 0.0f;
-	for (int i = 0; i < levelCount && rc == CVX_OK; i++) {
+	const int chained = std::min(levelCount, kMaxChainLevel);
+	rc = BuildLodChainDevice(ctx, dSrc, byteLength, dimX, dimY, dimZ, columnCount, chained, outStorage, outByteLength, outColumnCount, &totalMs);
+	for (int i = chained; i < levelCount && rc == CVX_OK; i++) {
 		float ms = 0.0f;
 		rc = DownsampleDevice(ctx, dSrc, dimX, dimY, dimZ, 0, columnCount, i + 1, &outStorage[i], &outByteLength[i], &outColumnCount[i], nullptr, &ms);
 		totalMs += ms;

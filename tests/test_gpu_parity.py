@@ -261,6 +261,49 @@ def test_world_with_device_built_lods_renders_identically(contexts):
         ctx.upload_world(ws)
 
 
+def _random_alpha_world(dims, seed, columns, segments):
+    """Columns of several vertical voxel segments (multi-run columns, segments that cross bucket boundaries of every level) with a random ARGB --
+    random ALPHA included -- per voxel: what the reference keeps of it at LOD j is the alpha of the voxel it inserts first (World.cs:85-94,101-127,
+    WordBuilder.cs:199-214), which the one-pass LOD chain has to carry through its sums (cvx_downsample.h, SumVoxel)."""
+    rng = np.random.default_rng(seed)
+    xs, ys, zs = [], [], []
+    for _ in range(columns):
+        x, z = int(rng.integers(0, dims[0])), int(rng.integers(0, dims[2]))
+        for _ in range(int(rng.integers(1, segments + 1))):
+            lo = int(rng.integers(0, dims[1]))
+            hi = min(dims[1] - 1, lo + int(rng.integers(0, 40)))
+            ys.extend(range(lo, hi + 1))
+            xs.extend([x] * (hi - lo + 1))
+            zs.extend([z] * (hi - lo + 1))
+    n = len(xs)
+    argb = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
+    return np.array(xs, np.int32), np.array(ys, np.int32), np.array(zs, np.int32), argb
+
+
+@pytest.mark.parametrize("dims,seed,columns,segments", [((64, 256, 64), 11, 2500, 4), ((32, 1024, 128), 12, 1500, 6), ((128, 64, 32), 13, 3000, 2)])
+def test_lod_chain_reads_lod0_once_and_matches_the_host_build(dims, seed, columns, segments):
+    """cvx_world_build_lods (round 5: level 1 from LOD 0, every further level from the sums of the one before it) against the host build of the same
+    chain -- which tests/test_world_model.py pins to an independent Python model -- on worlds whose voxels all differ in alpha: byte-identical
+    blobs for LOD 1 .. 5, i.e. integer averages from exact sums AND the reference's first-inserted alpha at every level."""
+    x, y, z, argb = _random_alpha_world(dims, seed, columns, segments)
+    ws = host.WorldSet.from_voxels(dims, x, y, z, argb, threads=4)
+    assert ws.lod_count == 6
+    ctx = gpu.Context(0)
+    try:
+        rebuilt = ctx.build_lods(ws)
+        assert rebuilt.lod_count == 6
+        for lod in range(1, 6):
+            got, want = rebuilt.storage(lod), ws.storage(lod)
+            assert got.size == want.size, f"LOD {lod}: {got.size} bytes vs {want.size}"
+            diff = np.flatnonzero(got != want)
+            assert diff.size == 0, f"LOD {lod}: first differing byte at {diff[0]} of {want.size} ({diff.size} differ)"
+            # the single-level entry point (LOD 0 -> LOD j directly, the kernels of rounds 1-4) agrees as well
+            blob, columns_, voxels, ms = ctx.downsample(ws, 0, lod)
+            assert np.array_equal(np.frombuffer(blob, dtype=np.uint8), want), f"cvx_world_downsample LOD {lod}"
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("split", [1, 2, 16, 64])
 def test_sub_tile_split_is_invisible(split, exp_library):
     """Small batches are rendered with tiles cut into sub-tiles of 64 / split rays per wave (DrawBatch); the raybuffers and the

@@ -1,6 +1,6 @@
 #!/bin/bash
-# final check of the tree as the driver will run it: smoke, the default bench line (traffic attached from profiles/, eight frames checked), GPU tests
-R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/r04v; mkdir -p $O; cd $R
-python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
-timeout 900 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"; python3 -c "
-import json; d=json.load(open('$O/bench_default.json')); r=d['roofline']; print(d['value'], d['ms_per_step'], r['frac'], r['traffic'], d['parity_checked'], d['parity']['frames'], d['parity']['pixels_compared'], d['parity']['pixels_differing'], d['latency']['ms'])"
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R
+mkdir -p gpurun_out/r05d
+timeout 600 python3 -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "lod_chain or downsample or device_built or scan" > gpurun_out/r05d/ds_tests.log 2>&1; echo "rc=$?"; tail -15 gpurun_out/r05d/ds_tests.log
+timeout 600 python3 tools/downsample_bench.py 2048 > gpurun_out/r05d/ds_bench.jsonl 2> gpurun_out/r05d/ds_bench.err; cat gpurun_out/r05d/ds_bench.jsonl; tail -3 gpurun_out/r05d/ds_bench.err

@@ -136,6 +136,17 @@ struct WaveRec {
 	                      "s_waitcnt lgkmcnt(0)\n v_add_f32 %5, %8, %5\n v_add_f32 %6, %8, %6\n v_add_f32 %7, %8, %7\n"))                           \
 	X(mix_salu2, "", T2("s_and_b64 s[20:21], s[20:21], s[22:23]\n s_or_b64 s[24:25], s[24:25], s[26:27]\n v_add_f32 %2, %8, %2\n v_add_f32 %3, %8, %3\n" \
 	                    "s_andn2_b64 s[22:23], s[22:23], s[24:25]\n s_xor_b64 s[26:27], s[26:27], s[20:21]\n v_add_f32 %6, %8, %6\n v_add_f32 %7, %8, %7\n")) \
+	/* round 5: does a scalar instruction cost an issue slot beside vector work, or only when the CU's one scalar unit is saturated?        \
+	   mix_salu2 is 50 % scalar: four SIMDs x 2 of 4 instructions ask the scalar unit for ~0.9 instructions per cycle -- its limit, whatever issue costs.       \
+	   The kernel's own ratio is ~1 scalar / branch per 2.6 vector: mix_salu1 (1 of 4) and mix_salu3of8 keep the scalar unit at <= 60 %. */                 \
+	X(mix_salu1, "", T2("s_and_b64 s[20:21], s[20:21], s[22:23]\n v_add_f32 %1, %8, %1\n v_add_f32 %2, %8, %2\n v_add_f32 %3, %8, %3\n"                 \
+	                    "s_or_b64 s[24:25], s[24:25], s[26:27]\n v_add_f32 %5, %8, %5\n v_add_f32 %6, %8, %6\n v_add_f32 %7, %8, %7\n"))                \
+	X(mix_salu3of8, "", T2("s_and_b64 s[20:21], s[20:21], s[22:23]\n v_add_f32 %1, %8, %1\n v_add_f32 %2, %8, %2\n s_or_b64 s[24:25], s[24:25], s[26:27]\n" \
+	                       "v_add_f32 %4, %8, %4\n v_add_f32 %5, %8, %5\n s_andn2_b64 s[22:23], s[22:23], s[24:25]\n v_add_f32 %7, %8, %7\n"))           \
+	X(mix_salu1_dep, "", T2("v_cmp_lt_f32 vcc, %8, %0\n s_and_b64 s[20:21], vcc, s[22:23]\n v_cndmask_b32_e64 %2, %8, %2, s[20:21]\n v_add_f32 %3, %8, %3\n" \
+	                        "v_add_f32 %4, %8, %4\n v_add_f32 %5, %8, %5\n v_add_f32 %6, %8, %6\n v_add_f32 %7, %8, %7\n"))                             \
+	X(mix_branch1, "", T2("v_add_f32 %0, %8, %0\n v_add_f32 %1, %8, %1\n v_add_f32 %2, %8, %2\n s_cbranch_execz 9f\n"                                   \
+	                      "v_add_f32 %4, %8, %4\n v_add_f32 %5, %8, %5\n v_add_f32 %6, %8, %6\n s_cbranch_execz 9f\n") "9:\n")                           \
 	X(mix_saveexec, "", T2("v_cmp_lt_f32 vcc, %8, %0\n s_and_saveexec_b64 s[20:21], vcc\n v_add_f32 %2, %8, %2\n s_or_b64 exec, exec, s[20:21]\n"    \
 	                       "v_add_f32 %4, %8, %4\n v_add_f32 %5, %8, %5\n v_add_f32 %6, %8, %6\n v_add_f32 %7, %8, %7\n"))                         \
 	X(mix_pk_fma, "", "v_add_f32 %0, %8, %0\n v_add_f32 %1, %8, %1\n v_add_f32 %2, %8, %2\n v_add_f32 %3, %8, %3\n v_add_f32 %4, %8, %4\n v_add_f32 %5, %8, %5\n v_pk_fma_f32 %[p0], %[p2], %[p2], %[p0]\n v_add_f32 %7, %8, %7\n" \
