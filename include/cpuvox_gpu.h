@@ -305,7 +305,10 @@ int cvx_world_downsample(cvx_context *ctx, const void *storage, int64_t byteLeng
                          void **outStorage, int64_t *outByteLength, int32_t *outColumnCount, int64_t *outVoxelCount, float *outDeviceMs);
 /* UnityManager.cs:328-331 (`worldLODs[i] = worldLODs[0].DownSample(i)`): LOD 1..levelCount from the LOD 0 blob with one
  * validation and one upload of it.  outStorage / outByteLength / outColumnCount are arrays of levelCount entries ([i] = LOD i+1);
- * each blob is released with cvx_free.  outDeviceMs (may be NULL) = summed device time. */
+ * each blob is released with cvx_free.  outDeviceMs (may be NULL) = device time of the whole chain.  LOD 0 is read ONCE: level 1
+ * is built from its colours, every further level (up to 7) from the level before it through exact per-voxel sums, which gives the
+ * bytes of `DownSample(i)` applied to LOD 0 (integer averages of the LOD-0 voxels, the first inserted voxel's alpha); levels above 7
+ * are built from LOD 0 directly like cvx_world_downsample does.  Device memory while it runs: ~7 x the LOD 0 blob. */
 int cvx_world_build_lods(cvx_context *ctx, const void *storage, int64_t byteLength, int dimX, int dimY, int dimZ, int columnCount, int levelCount,
                          void **outStorage, int64_t *outByteLength, int32_t *outColumnCount, float *outDeviceMs);
 void cvx_free(void *p);
