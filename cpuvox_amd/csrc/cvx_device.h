@@ -29,7 +29,8 @@ struct DevWorldLevel {
 	//         colorsBase   = element index (inside this level's pool) of the column's first colour (RLEColumn.ColorPointer, World.cs:185)
 	//         overflowBase = index into this level's run list of solid run 2 (valid when solidCount > 2)
 	//   [1] = solid runs 0 and 1 (top-down order), two words each:
-	//         w0 = start | length << 16      start = voxels (of this LOD) between the top of the column and the run
+	//         w0 = bottomY | (topY - 1) << 16      the run's span [bottomY, topY] in LOD-0 voxels (topY = dimY - (voxels of this LOD above the run << lod);
+	//              round 5: rounds 1-4 stored start | length << 16 and the kernel shifted / subtracted them into these two numbers three times per drawn column)
 	//         w1 = colorsIndex | elementIndex << 16   elementIndex = 1-based position of the run among ALL elements, top-down
 	//              (only the counting variant reads it: it restores the reference's element count E)
 	// Record of column (x, z) (LOD-0 coordinates): cx = x >> shift, cz = z >> shift; index = (cx << rowShift) + cz -- row-major, so that

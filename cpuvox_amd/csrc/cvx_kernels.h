@@ -652,12 +652,14 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		// scanned when their turn comes.  Same runs, same order per lane as the walk of the counting build (and the oracle).
 		bool vis0 = false, vis1 = false;
 		int ovNext = 0; // next run beyond the record to look at: 2, 3, ... (top-down walk) or solidCount - 1, ... 2 (bottom-up walk)
-		// world-space span of a run word {start | length << 16}: [top - length, top] in LOD-0 voxels (integers, see the walk below)
+		// world-space span of a run word {bottomY | (topY - 1) << 16} (cvx_device.h): LOD-0 voxels, integers below 2^17 -- exact as floats, and the
+		// numbers the reference accumulates (see the walk below)
 		auto runSpan = [&](uint32_t w0, float &bottom, float &top) {
-			const int t = worldMaxYInt - (int)((w0 & 0xFFFFu) << lod);
-			top = (float)t;
-			bottom = (float)(t - (int)((w0 >> 16) << lod));
+			bottom = (float)(w0 & 0xFFFFu);
+			top = (float)(w0 >> 16) + 1.0f;
 		};
+		// RLEElement.Length of that run: its height in voxels of this LOD
+		auto runLength = [&](uint32_t w0) -> int { return (int)(((w0 >> 16) + 1u - (w0 & 0xFFFFu)) >> lod); };
 		if (!COUNT) {
 			float b0, t0, b1, t1;
 			runSpan(queue.x, b0, t0);
@@ -687,7 +689,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 					ovNext += DIR > 0 ? 1 : -1;
 					runSpan(run.x, elementBoundsMin, elementBoundsMax);
 					if (!(elementBoundsMin > worldBoundsMax) && !(elementBoundsMax < worldBoundsMin)) {
-						elementLength = (int)(run.x >> 16);
+						elementLength = runLength(run.x);
 						elementColorsIndex = (int)(run.y & 0xFFFFu);
 						found = true;
 						break;
@@ -709,12 +711,12 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 					float spanMin, spanMax;
 					runSpan(w0, spanMin, spanMax);
 					if (DIR > 0) { // (nothing found yet: a lane that takes nothing here either scans on below or leaves the loop)
-						elementLength = (int)(w0 >> 16);
+						elementLength = runLength(w0);
 						elementColorsIndex = (int)(w1 & 0xFFFFu);
 						elementBoundsMin = spanMin;
 						elementBoundsMax = spanMax;
 					} else {
-						elementLength = take ? (int)(w0 >> 16) : elementLength;
+						elementLength = take ? runLength(w0) : elementLength;
 						elementColorsIndex = take ? (int)(w1 & 0xFFFFu) : elementColorsIndex;
 						elementBoundsMin = take ? spanMin : elementBoundsMin;
 						elementBoundsMax = take ? spanMax : elementBoundsMax;
@@ -739,14 +741,12 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 					w1 = run.y;
 				}
 				solidIndex++;
-				elementLength = (int)(w0 >> 16);
+				elementLength = runLength(w0);
 				elementColorsIndex = (int)(w1 & 0xFFFFu);
 				if (COUNT) { consumed = DIR > 0 ? (w1 >> 16) : (header.z >> 16) + 1u - (w1 >> 16); } // position among all elements in walk order
 				// The run's world-space span.  Top-down the reference accumulates it from worldMaxY (:429-431,449-451), bottom-up from 0
 				// (:433-435,453-455): integer sums either way, and the runs of a column add up to its height, so both are these.
-				const int top = worldMaxYInt - (int)(w0 & 0xFFFFu) * voxelScale;
-				elementBoundsMax = (float)top;
-				elementBoundsMin = (float)(top - elementLength * voxelScale);
+				runSpan(w0, elementBoundsMin, elementBoundsMax);
 				if (elementBoundsMin > worldBoundsMax) {
 					if (DIR < 0) { solidIndex = solidCount + 1; break; } else { continue; }
 				}
@@ -1214,6 +1214,7 @@ __global__ __launch_bounds__(CVX_WAVE, CVX_WAVES_PER_SIMD) void render_kernel(co
 		uint32_t todo = 0u;
 		if (active && leader) { todo = ~seen[w << sshift] & range_mask(w, omin, omax); }
 		const int base = w << 5;
+		if (!COUNT && __ballot(todo != 0u) == 0ull) { continue; } // (a word every ray of the tile has filled -- the ground half of a frame: 3 instructions instead of 32 bit tests; round 5: -0.5 %)
 #pragma unroll 4
 		for (int b = 0; b < 32; b++) {
 			if ((todo >> b) & 1u) {

@@ -123,7 +123,9 @@ int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byt
 				const uint32_t raw = elements[off + 1 + r];
 				const uint32_t length = raw >> 16;
 				if ((int16_t)(raw & 0xFFFFu) >= 0) {
-					const uint2 run = uint2{ start | (length << 16), (raw & 0xFFFFu) | ((uint32_t)(r + 1) << 16) };
+					// the run's span in LOD-0 voxels, ready for the kernel: [bottomY, topY] with topY = dimY - (start << lod) (<= 65536: stored minus one)
+					const uint32_t topY = (uint32_t)dimY - (start << lod), bottomY = topY - (length << lod);
+					const uint2 run = uint2{ bottomY | ((topY - 1u) << 16), (raw & 0xFFFFu) | ((uint32_t)(r + 1) << 16) };
 					if (solid < 2) {
 						first[solid] = run;
 					} else {

@@ -1,8 +1,6 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-mkdir -p gpurun_out/r05u
-timeout 900 python3 tools/ab_fast.py "libcpuvox_gpu.so libcpuvox_gpu_w3.so libcpuvox_gpu_w2.so" --width 3840 --height 2160 --frames 64 --steps 2 --rounds 4 --contexts 2 --check-frames 4 --oracle-frames 1 > gpurun_out/r05u/w4k.txt 2>&1
-tail -6 gpurun_out/r05u/w4k.txt
-timeout 900 python3 tools/ab_fast.py "libcpuvox_gpu.so libcpuvox_gpu_w3.so" --frames 256 --steps 2 --rounds 3 --check-frames 2 --oracle-frames 0 > gpurun_out/r05u/w1080.txt 2>&1
-tail -4 gpurun_out/r05u/w1080.txt
+mkdir -p gpurun_out/r05v
+timeout 900 python3 tools/ab_fast.py "libcpuvox_gpu.so libcpuvox_gpu_skyskip.so" --frames 256 --steps 3 --rounds 5 --contexts 3 --check-frames 16 --latency 100 > gpurun_out/r05v/runyy.txt 2>&1
+tail -5 gpurun_out/r05v/runyy.txt
