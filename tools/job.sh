@@ -1,6 +1,7 @@
 #!/bin/bash
+# round-5 final: full GPU suite + soaks + the whole profile collection with the FINAL library
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-mkdir -p gpurun_out/r05v
-timeout 900 python3 tools/ab_fast.py "libcpuvox_gpu.so libcpuvox_gpu_skyskip.so" --frames 256 --steps 3 --rounds 5 --contexts 3 --check-frames 16 --latency 100 > gpurun_out/r05v/runyy.txt 2>&1
-tail -5 gpurun_out/r05v/runyy.txt
+mkdir -p gpurun_out/r05z
+timeout 1000 python3 -m pytest tests -m gpu -x -q > gpurun_out/r05z/gputests.log 2>&1; echo "gputests rc=$?"; tail -3 gpurun_out/r05z/gputests.log
+bash tools/profile_round.sh r05 > gpurun_out/profile_round_r05.log 2>&1; tail -4 gpurun_out/profile_round_r05.log | cut -c1-300
