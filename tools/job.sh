@@ -1,7 +1,6 @@
 #!/bin/bash
-# round-5 final: full GPU suite + soaks + the whole profile collection with the FINAL library
+# round-5 final library: long parity soak (20 000 random poses, counting + rendering build) + the 1000 benchmark poses
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-mkdir -p gpurun_out/r05z
-timeout 1000 python3 -m pytest tests -m gpu -x -q > gpurun_out/r05z/gputests.log 2>&1; echo "gputests rc=$?"; tail -3 gpurun_out/r05z/gputests.log
-bash tools/profile_round.sh r05 > gpurun_out/profile_round_r05.log 2>&1; tail -4 gpurun_out/profile_round_r05.log | cut -c1-300
+mkdir -p gpurun_out/r05s
+timeout 1100 python3 tools/soak.py 5000 > gpurun_out/r05s/soak_long.txt 2>&1; echo "soak rc=$?"; tail -2 gpurun_out/r05s/soak_long.txt
