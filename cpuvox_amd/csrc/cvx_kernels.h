@@ -48,12 +48,7 @@ __device__ __forceinline__ void st_pixel_stream(gptr_tile tile, uint32_t laneByt
 // (timing builds of rounds 2-4 -- no stores, no colour loads, constant texture index, lane-major tiles, flat addressing, no block-layout hints, no
 // drain at the end of a drawn column -- are archived in tools/patches/exp_timing_switches.patch with their numbers in profiles/r02..r04_experiments.md)
 #define st_pixel_loop st_pixel
-#ifdef CVX_V_NTCOLOR
-__device__ __forceinline__ uint32_t ld1_nt(gptr_arena arena, uint32_t byteOff) { return __builtin_nontemporal_load((const CVX_GLOBAL uint32_t *)(arena + byteOff)); }
-#define ld_color ld1_nt
-#else
 #define ld_color ld1
-#endif
 
 // Byte offset (inside the level's table) of the 32-byte record of LOD column (cx, cz): row-major, cvx_device.h
 __device__ __forceinline__ uint32_t record_offset(int cx, int cz, int rowShift)
@@ -886,19 +881,6 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 									int colorIdx = m_clampi(f2i_floor(u), 0, elementLength - 1) + elementColorsIndex;
 									return worldColumnColorsOff + (uint32_t)colorIdx * 4u;
 								};
-#ifdef CVX_V_FAKE_EMIT /* timing experiment only (wrong pictures): what the column loop costs when a side's pixels leave as a 40-byte span record */
-								{
-									const uint32_t rowClamped = (uint32_t)min(max(w << 5, 0), 1000);
-									CVX_GLOBAL uint8_t *at = tileOut + (rowClamped * 256u + (laneByteOff << 2));
-									float pad_ = boundsX;
-									asm volatile("v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0\n v_mov_b32 %0, %0" : "+v"(pad_));
-									*(CVX_GLOBAL u32x4 *)at = u32x4{ todo, (uint32_t)w, __float_as_uint(pad_), __float_as_uint(boundsY) };
-									*(CVX_GLOBAL u32x4 *)(at + 1024) = u32x4{ __float_as_uint(uvAx), __float_as_uint(uvBx), __float_as_uint(uvAy), __float_as_uint(uvBy) };
-									*(CVX_GLOBAL u32x2 *)(at + 2048) = u32x2{ (uint32_t)elementLength, worldColumnColorsOff + (uint32_t)elementColorsIndex * 4u };
-									todo = 0u;
-								}
-								if (false)
-#endif
 								// Two pixels per trip: both colour loads are in flight before the first store waits for its colour (a load's
 								// latency is what a trip costs, not its arithmetic).  Same pixels, same order of stores per lane.
 								do {
