@@ -42,7 +42,7 @@ __device__ __forceinline__ uint32_t ld1(gptr_arena arena, uint32_t byteOff) { re
 typedef CVX_GLOBAL uint8_t *gptr_tile;
 __device__ __forceinline__ void st_pixel(gptr_tile tile, uint32_t laneByteOff, int y, uint32_t argb) { *(CVX_GLOBAL uint32_t *)(tile + ((uint32_t)y * (CVX_WAVE * 4u) + laneByteOff)) = argb; }
 // The skybox pass (half of all pixels: whole 256-byte rows of the tile, written once, read by nobody in this launch) stores non-temporally: the rows
-// stream past the L2 instead of evicting world records from it.  Round 5, A/B on one box: 13.41 -> 13.16 ms per 256 frames (-1.9 %).  The scattered 4-byte
+// stream past the L2 instead of evicting world records from it.  Round 5, A/B on one box, three contexts per build: 13.30 .. 13.39 -> 13.18 .. 13.28 ms per 256 frames (-1.1 %).  The scattered 4-byte
 // stores of the pixel loops must NOT: they rely on the L2 to combine neighbours into whole lines (`nt` there: +7.8 %).
 __device__ __forceinline__ void st_pixel_stream(gptr_tile tile, uint32_t laneByteOff, int y, uint32_t argb) { __builtin_nontemporal_store(argb, (CVX_GLOBAL uint32_t *)(tile + ((uint32_t)y * (CVX_WAVE * 4u) + laneByteOff))); }
 // (timing builds of rounds 2-4 -- no stores, no colour loads, constant texture index, lane-major tiles, flat addressing, no block-layout hints, no

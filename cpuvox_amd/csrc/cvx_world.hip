@@ -522,7 +522,15 @@ int cvx_world_build_lods(cvx_context *ctx, const void *storage, int64_t byteLeng
 	float totalMs = 0.0f;
 	const int chained = std::min(levelCount, kMaxChainLevel);
 	rc = BuildLodChainDevice(ctx, dSrc, byteLength, dimX, dimY, dimZ, columnCount, chained, outStorage, outByteLength, outColumnCount, &totalMs);
-	for (int i = chained; i < levelCount && rc == CVX_OK; i++) {
+	int first = chained;
+	if (rc == CVX_ERR_HIP) { // (e.g. not enough device memory for the chain's pools, ~7 x the LOD 0 blob: level by level from LOD 0 instead, like rounds 1-4)
+		(void)hipGetLastError();
+		for (int i = 0; i < levelCount; i++) { outStorage[i] = nullptr; }
+		totalMs = 0.0f;
+		first = 0;
+		rc = CVX_OK;
+	}
+	for (int i = first; i < levelCount && rc == CVX_OK; i++) {
 		float ms = 0.0f;
 		rc = DownsampleDevice(ctx, dSrc, dimX, dimY, dimZ, 0, columnCount, i + 1, &outStorage[i], &outByteLength[i], &outColumnCount[i], nullptr, &ms);
 		totalMs += ms;
