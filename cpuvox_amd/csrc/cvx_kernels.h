@@ -881,8 +881,9 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 									int colorIdx = m_clampi(f2i_floor(u), 0, elementLength - 1) + elementColorsIndex;
 									return worldColumnColorsOff + (uint32_t)colorIdx * 4u;
 								};
-								// Two pixels per trip: both colour loads are in flight before the first store waits for its colour (a load's
-								// latency is what a trip costs, not its arithmetic).  Same pixels, same order of stores per lane.
+								// Up to four pixels per trip: all their colour loads are in flight before the first store waits for its colour (a load's
+								// latency is what a trip costs, not its arithmetic).  Same pixels, same order of stores per lane.  (Two per trip until
+								// round 5; four: -1.7 % at 3840 x 2160, -0.6 % at 1080p, where 35 % of the trips have a second pixel.)
 								do {
 									CVX_COUNT(5);
 									const int y0 = (w << 5) + (__ffs((int)todo) - 1);
@@ -891,16 +892,35 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 									const bool second = todo != 0u;
 									int y1 = y0;
 									uint32_t c1 = 0u;
+									bool third = false, fourth = false;
+									int y2 = y0, y3 = y0;
+									uint32_t c2 = 0u, c3 = 0u;
 									if (second) {
 										y1 = (w << 5) + (__ffs((int)todo) - 1);
 										todo &= todo - 1u;
 										c1 = ld_color(arena, colourOffset(y1));
+										third = todo != 0u;
+										if (third) {
+											y2 = (w << 5) + (__ffs((int)todo) - 1);
+											todo &= todo - 1u;
+											c2 = ld_color(arena, colourOffset(y2));
+											fourth = todo != 0u;
+											if (fourth) {
+												y3 = (w << 5) + (__ffs((int)todo) - 1);
+												todo &= todo - 1u;
+												c3 = ld_color(arena, colourOffset(y3));
+											}
+										}
 									}
 									st_pixel_loop(tileOut, laneByteOff, y0, c0);
 									if (second) {
 										st_pixel_loop(tileOut, laneByteOff, y1, c1);
+										if (third) {
+											st_pixel_loop(tileOut, laneByteOff, y2, c2);
+											if (fourth) { st_pixel_loop(tileOut, laneByteOff, y3, c3); }
+										}
 									}
-									if (COUNT) { cnt.C += second ? 2u : 1u; cnt.P += second ? 2u : 1u; }
+									if (COUNT) { const unsigned int n_ = 1u + (second ? 1u : 0u) + (third ? 1u : 0u) + (fourth ? 1u : 0u); cnt.C += n_; cnt.P += n_; }
 								} while (todo != 0u);
 							}
 						}
