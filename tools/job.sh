@@ -1,8 +1,8 @@
 #!/bin/bash
+# round-5 final: full GPU suite + the whole profile collection with the FINAL library
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
-mkdir -p gpurun_out/r05x
-timeout 900 python3 tools/ab_fast.py "libcpuvox_gpu.so libcpuvox_gpu_pix4.so" --width 3840 --height 2160 --frames 64 --steps 2 --rounds 4 --contexts 2 --check-frames 4 --oracle-frames 1 > gpurun_out/r05x/pix4_4k.txt 2>&1
-tail -4 gpurun_out/r05x/pix4_4k.txt
-timeout 900 python3 tools/ab_fast.py "libcpuvox_gpu.so libcpuvox_gpu_pix4.so" --frames 256 --steps 2 --rounds 4 --contexts 2 --check-frames 8 --oracle-frames 0 > gpurun_out/r05x/pix4_1080.txt 2>&1
-tail -3 gpurun_out/r05x/pix4_1080.txt
+mkdir -p gpurun_out/r05z
+timeout 1000 python3 -m pytest tests -m gpu -x -q > gpurun_out/r05z/gputests.log 2>&1; echo "gputests rc=$?"; tail -3 gpurun_out/r05z/gputests.log
+timeout 600 python3 tools/soak.py 1000 > gpurun_out/r05z/soak.txt 2>&1; echo "soak rc=$?"; tail -1 gpurun_out/r05z/soak.txt
+bash tools/profile_round.sh r05 > gpurun_out/profile_round_r05.log 2>&1; tail -1 gpurun_out/profile_round_r05.log | cut -c1-100
