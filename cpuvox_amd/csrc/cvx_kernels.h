@@ -565,8 +565,25 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			// CameraData.cs:103,111.  frustumBounds = (integer pixel in [-1, 16385]) -/+ 0.501: magnitude in [0.499, 16386], always "safe"
 			const float invFrustumMin = quot_safe(1.0f, recip_safe(frustumBoundsMin)), invFrustumMax = quot_safe(1.0f, recip_safe(frustumBoundsMax));
 			bool straddlesLast, straddlesNext;
-			const bool clippedLast = clip_world_bounds(camSpaceMinLast, camSpaceMaxLast, frustumBoundsMin, frustumBoundsMax, invFrustumMin, invFrustumMax, clipLastMinLerp, clipLastMaxLerp, straddlesLast);
-			const bool clippedNext = clip_world_bounds(camSpaceMinNext, camSpaceMaxNext, frustumBoundsMin, frustumBoundsMax, invFrustumMin, invFrustumMax, clipNextMinLerp, clipNextMaxLerp, straddlesNext);
+			bool clippedLast, clippedNext;
+			{
+				const auto straddle = [&](f3 pMin, f3 pMax) { return ((int)!(pMin.x > pMin.z * frustumBoundsMax) & (int)(pMin.x < pMin.z * frustumBoundsMin) & (int)(pMax.x > pMax.z * frustumBoundsMax)) != 0; };
+				const bool both = ((int)straddle(camSpaceMinLast, camSpaceMaxLast) & (int)straddle(camSpaceMinNext, camSpaceMaxNext)) != 0;
+				// Round 5: when EVERY lane that clips here sees the column's foot below and its top above the window at both ends -- clip_world_bounds' straddle case, the
+				// ordinary view of a world column -- the four lerps are its clip_min against frustumBoundsMin and clip_max against frustumBoundsMax, nothing is
+				// clipped away, and the wave skips the selects and the flag algebra of the general form (same divisions on the same operands: -0.9 %)
+				if (__ballot(!both) == 0ull) {
+					clipLastMinLerp = clip_min(camSpaceMinLast, camSpaceMaxLast, invFrustumMin);
+					clipLastMaxLerp = clip_max(camSpaceMinLast, camSpaceMaxLast, invFrustumMax);
+					clipNextMinLerp = clip_min(camSpaceMinNext, camSpaceMaxNext, invFrustumMin);
+					clipNextMaxLerp = clip_max(camSpaceMinNext, camSpaceMaxNext, invFrustumMax);
+					clippedLast = clippedNext = false;
+					straddlesLast = straddlesNext = true;
+				} else {
+					clippedLast = clip_world_bounds(camSpaceMinLast, camSpaceMaxLast, frustumBoundsMin, frustumBoundsMax, invFrustumMin, invFrustumMax, clipLastMinLerp, clipLastMaxLerp, straddlesLast);
+					clippedNext = clip_world_bounds(camSpaceMinNext, camSpaceMaxNext, frustumBoundsMin, frustumBoundsMax, invFrustumMin, invFrustumMax, clipNextMinLerp, clipNextMaxLerp, straddlesNext);
+				}
+			}
 
 			// (:297-299 leaves here when both ends are outside the window; that exit is taken together with the next one below --
 			// nothing in between has an effect that survives the end of the ray)
