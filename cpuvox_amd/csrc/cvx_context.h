@@ -43,10 +43,11 @@ struct cvx_context {
 	// world: every level is laid out on the host by cvx_world_upload (records, run list, element pool) and placed into ONE
 	// device arena by the next draw (SyncWorld); levels that were not uploaded again are copied over from the old arena
 	struct HostLevel {
-		std::vector<uint4> records;     // 2 per column, row-major (cvx_device.h); empty once the level lives in the arena
-		std::vector<uint2> runs;
+		std::vector<uint4> records;     // 1 per column, row-major (cvx_device.h); empty once the level lives in the arena
+		std::vector<uint2> runs;        // run list: every solid run of the columns whose record cannot hold them
+		std::vector<uint2> counts;      // per column, what only the counting build reads
 		std::vector<uint32_t> elements; // padded with zeroed guard entries on both sides
-		size_t recordsBytes = 0, runsBytes = 0, elementsBytes = 0;
+		size_t recordsBytes = 0, runsBytes = 0, countsBytes = 0, elementsBytes = 0;
 		bool pending = false;           // host vectors hold data that is not in the arena yet
 		int rowShift = 0;
 	};

@@ -1,9 +1,8 @@
 // cvx_device.h -- device-side data layout of libcpuvox_gpu (gfx950 only).
 //
-// World: ONE arena for all six LODs.  Per LOD a table of 32-byte column records in 8 x 8 tiles (a DDA step to a
-// neighbouring column stays inside a 2 KB tile most of the time; World.GetIndexKnownInBounds' x-major order, World.cs:
-// 145-149, puts x-neighbours dimZ * 32 bytes apart), built on upload from the reference's 12-byte headers (World.cs:161-169),
-// an overflow list of solid runs for the few columns with more than two, and the element pool in the reference's own
+// World: ONE arena for all six LODs.  Per LOD a row-major table of 16-byte column records (World.GetIndexKnownInBounds' x-major order, World.cs:
+// 145-149), built on upload from the reference's 12-byte headers (World.cs:161-169),
+// a run list for the few columns whose record cannot hold their runs, and the element pool in the reference's own
 // order [guard][run 0..n-1][guard][colour 0..s-1] (World.cs:163-165), from which the kernel reads the colours.  Everything
 // is addressed with 32-bit byte offsets from the arena base (one scalar register pair for the whole wave; the arena is
 // limited to 4 GiB).
@@ -20,30 +19,39 @@
 #define CVX_SKYBOX_ARGB 0x191919FFu /* ColorARGB32(25,25,25): bytes FF 19 19 19 (DrawSegmentRayJob.cs:702) */
 
 struct DevWorldLevel {
-	// One 32-byte record per column.  The reference walks every RLE element of a column (air runs only move the bounds,
-	// World.cs:245-259), from the top down (ITERATION_DIRECTION +1) or from the bottom up (-1); the record holds the SOLID
-	// runs only, top-down, each with its distance from the top of the column -- upload checks that the runs of a column add up
-	// to the column height (the reference's builder always emits such columns, WordBuilder.cs:232-258), so the same numbers
-	// give the positions the bottom-up walk accumulates, and one table serves both directions (the kernel walks it backwards):
-	//   [0] = {colorsBase, solidCount | worldMin << 16, worldMax | runCount << 16, overflowBase}
-	//         colorsBase   = element index (inside this level's pool) of the column's first colour (RLEColumn.ColorPointer, World.cs:185)
-	//         overflowBase = index into this level's run list of solid run 2 (valid when solidCount > 2)
-	//   [1] = solid runs 0 and 1 (top-down order), two words each:
-	//         w0 = bottomY | (topY - 1) << 16      the run's span [bottomY, topY] in LOD-0 voxels (topY = dimY - (voxels of this LOD above the run << lod);
-	//              round 5: rounds 1-4 stored start | length << 16 and the kernel shifted / subtracted them into these two numbers three times per drawn column)
-	//         w1 = colorsIndex | elementIndex << 16   elementIndex = 1-based position of the run among ALL elements, top-down
-	//              (only the counting variant reads it: it restores the reference's element count E)
+	// One 16-byte record per column (round 5; rounds 1-4: 32 bytes -- the column's header and its first two solid runs with everything the
+	// counting build wants beside them.  Three quarters of the columns of a terrain hold ONE solid run whose span is the header's
+	// [worldMin, worldMax], nearly all others two or three: the record now keeps what the RENDERING build reads, a 128-byte line holds eight
+	// columns instead of four, and the column loop fetches one dwordx4 per step instead of two).
+	// The reference walks every RLE element of a column (air runs only move the bounds, World.cs:245-259), from the top down
+	// (ITERATION_DIRECTION +1) or from the bottom up (-1); the kernel iterates the SOLID runs only, top-down numbering, each as its span
+	// [bottomY, topY] in LOD-0 voxels (topY = dimY - (voxels of this LOD above the run << lod); upload checks that the runs of a column add
+	// up to the column height -- the reference's builder always emits such columns, WordBuilder.cs:232-258 -- so the same numbers are what
+	// the bottom-up walk accumulates).
+	//   x = code << 30 | colorsBase      colorsBase = element index (inside this level's pool) of the column's first colour (RLEColumn.ColorPointer, World.cs:185; >= 3)
+	//   y = worldMin | worldMax << 16    RLEColumn.WorldMin / WorldMax as the blob has them (World.cs:161-169): what the cull of every column step reads
+	//   x == 0: RunCount == 0 (the empty column, all four words 0)
+	//   code 1 .. 3 = the number of solid runs, for a column the builder's invariants hold for -- the top run ends at worldMax, the lowest one stands on
+	//           worldMin, and every ColorsIndex is the sum of the lengths of the solid runs above it (WordBuilder.cs:181-268 emits nothing else; the
+	//           kernel derives the index from the spans).  run 0 = [w.lo, worldMax], run 1 = [z.lo, w.hi + 1], run 2 = [worldMin, z.hi + 1]:
+	//           one run:  w = y;   two: w = bottom0 | (top1 - 1) << 16, z = worldMin;   three: w likewise, z = bottom1 | (top2 - 1) << 16
+	//   code 0, x != 0: anything else ("listed": more runs, no solid run, bounds or colour indices of another shape): z = index into this level's run
+	//           list of the column's block (an even index: 16-byte aligned), w = solidCount.  A block holds ALL solid runs of the column, two words each:
+	//           w0 = bottomY | (topY - 1) << 16,  w1 = colorsIndex | elementIndex << 16  (elementIndex = 1-based position of the run among ALL
+	//           elements, top-down; only the counting variant reads it).  The kernel may read two entries at any block, also an empty one.
+	// `counts` (only the counting variant reads it, it restores the reference's element count E): per column {RunCount | elementIndex of solid
+	// run 0 << 16, elementIndex of run 1 | elementIndex of run 2 << 16}.
 	// Record of column (x, z) (LOD-0 coordinates): cx = x >> shift, cz = z >> shift; index = (cx << rowShift) + cz -- row-major, so that
-	// a DDA step moves the record address by a per-ray constant (+- 32 << rowShift bytes along x, +- 32 along z) and the column loop adds
-	// instead of recomputing it (round 2's 8 x 8 tiles cost 14 vector instructions per step and bought nothing: a 128-byte line holds four
-	// z-neighbours either way).  A table is preceded and followed by at least one row + 64 bytes of arena that belong to nothing: a ray
-	// that leaves the world fetches (and never looks at) the record one step outside.
+	// a DDA step moves the record address by a per-ray constant (+- 16 << rowShift bytes along x, +- 16 along z) and the column loop adds
+	// instead of recomputing it (round 2's 8 x 8 tiles cost 14 vector instructions per step and bought nothing).  A table is preceded and
+	// followed by at least one row + 64 bytes of arena that belong to nothing: a ray that leaves the world fetches (and never looks at) the
+	// record one step outside.
 	uint32_t recordsOff;  // byte offsets from DevWorld::arena
-	uint32_t runsOff;     // uint2 per solid run k >= 2
+	uint32_t runsOff;     // run list: uint2 per solid run of the listed columns
 	uint32_t elementsOff; // the reference's element pool (RLEElement / ColorARGB32); the kernel reads colours only
 	int32_t shift;        // lod
 	int32_t rowShift;     // log2 of the records per row (columns of this level along z)
-	int32_t pad_;
+	uint32_t countsOff;   // uint2 per column, indexed like the records
 };
 
 struct DevWorld {

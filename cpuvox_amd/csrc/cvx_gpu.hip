@@ -309,17 +309,18 @@ int SyncWorld(cvx_context *ctx)
 				return Fail(ctx, CVX_ERR_NOT_READY, "world LOD %d has not been uploaded (UnityManager.LOD_LEVELS = 6)", i);
 			}
 		}
-		// One arena for all levels: [guard | records | guard | run list | element pool] per level, 256-byte aligned parts, 32-bit offsets.
+		// One arena for all levels: [guard | records | guard | run list | counts | element pool] per level, 256-byte aligned parts, 32-bit offsets.
 		// guard = one row of records + 64 bytes that belong to nothing (cvx_device.h: the fetch of a ray that has just left the world).
 		DevWorld next = ctx->hostWorld;
 		size_t cursor = 0;
 		auto place = [&](size_t bytes) { const size_t at = cursor; cursor = (cursor + bytes + 255) & ~(size_t)255; return at; };
-		size_t recordsAt[CVX_LOD_LEVELS], runsAt[CVX_LOD_LEVELS], elementsAt[CVX_LOD_LEVELS];
+		size_t recordsAt[CVX_LOD_LEVELS], runsAt[CVX_LOD_LEVELS], countsAt[CVX_LOD_LEVELS], elementsAt[CVX_LOD_LEVELS];
 		for (int i = 0; i < CVX_LOD_LEVELS; i++) {
 			const cvx_context::HostLevel &H = ctx->hostLevel[i];
-			const size_t guard = (((size_t)32 << H.rowShift) + 64 + 255) & ~(size_t)255;
+			const size_t guard = (((size_t)16 << H.rowShift) + 64 + 255) & ~(size_t)255;
 			recordsAt[i] = place(guard + H.recordsBytes + guard) + guard;
 			runsAt[i] = place(H.runsBytes);
+			countsAt[i] = place(H.countsBytes);
 			elementsAt[i] = place(H.elementsBytes);
 		}
 		if (cursor >= ((size_t)1 << 32)) {
@@ -334,11 +335,13 @@ int SyncWorld(cvx_context *ctx)
 			if (H.pending) {
 				e = hipMemcpy(arena + recordsAt[i], H.records.data(), H.recordsBytes, hipMemcpyHostToDevice);
 				if (e == hipSuccess) { e = hipMemcpy(arena + runsAt[i], H.runs.data(), H.runsBytes, hipMemcpyHostToDevice); }
+				if (e == hipSuccess) { e = hipMemcpy(arena + countsAt[i], H.counts.data(), H.countsBytes, hipMemcpyHostToDevice); }
 				if (e == hipSuccess) { e = hipMemcpy(arena + elementsAt[i], H.elements.data(), H.elementsBytes, hipMemcpyHostToDevice); }
 			} else { // unchanged level: it lives in the old arena
 				const DevWorldLevel &old = ctx->hostWorld.level[i];
 				e = hipMemcpy(arena + recordsAt[i], ctx->arena + old.recordsOff, H.recordsBytes, hipMemcpyDeviceToDevice);
 				if (e == hipSuccess) { e = hipMemcpy(arena + runsAt[i], ctx->arena + old.runsOff, H.runsBytes, hipMemcpyDeviceToDevice); }
+				if (e == hipSuccess) { e = hipMemcpy(arena + countsAt[i], ctx->arena + old.countsOff, H.countsBytes, hipMemcpyDeviceToDevice); }
 				if (e == hipSuccess) { e = hipMemcpy(arena + elementsAt[i], ctx->arena + old.elementsOff - 16, H.elementsBytes, hipMemcpyDeviceToDevice); }
 			}
 		}
@@ -350,6 +353,7 @@ int SyncWorld(cvx_context *ctx)
 			cvx_context::HostLevel &H = ctx->hostLevel[i];
 			std::vector<uint4>().swap(H.records);
 			std::vector<uint2>().swap(H.runs);
+			std::vector<uint2>().swap(H.counts);
 			std::vector<uint32_t>().swap(H.elements);
 			H.pending = false;
 			DevWorldLevel &L = next.level[i];
@@ -358,7 +362,7 @@ int SyncWorld(cvx_context *ctx)
 			L.elementsOff = (uint32_t)(elementsAt[i] + 16); // past the leading guard entries (kPoolPad * 4 bytes)
 			L.shift = i;
 			L.rowShift = H.rowShift;
-			L.pad_ = 0;
+			L.countsOff = (uint32_t)countsAt[i];
 		}
 		if (ctx->arena) { (void)hipFree(ctx->arena); }
 		ctx->arena = arena;

@@ -50,10 +50,10 @@ __device__ __forceinline__ void st_pixel_stream(gptr_tile tile, uint32_t laneByt
 #define st_pixel_loop st_pixel
 #define ld_color ld1
 
-// Byte offset (inside the level's table) of the 32-byte record of LOD column (cx, cz): row-major, cvx_device.h
+// Byte offset (inside the level's table) of the 16-byte record of LOD column (cx, cz): row-major, cvx_device.h
 __device__ __forceinline__ uint32_t record_offset(int cx, int cz, int rowShift)
 {
-	return (((uint32_t)cx << rowShift) + (uint32_t)cz) << 5;
+	return (((uint32_t)cx << rowShift) + (uint32_t)cz) << 4;
 }
 
 // ---- Unity.Mathematics scalar semantics (math.cs 1.2.6) --------------------
@@ -246,7 +246,7 @@ __device__ __forceinline__ bool dda_step_to_world_intersection(DDA &d, float dim
 struct ColumnCursor {
 	int pos, posStepX, posStepZ;      // x * 65536 + z and what a step along x / z adds to it
 	uint32_t rec;                     // arena byte offset of the column's record
-	int recStepX, recStepZ;           // +- (32 << rowShift), +- 32
+	int recStepX, recStepZ;           // +- (16 << rowShift), +- 16
 };
 __device__ __forceinline__ void cursor_set(ColumnCursor &c, const DDA &d, const DevWorldLevel &level, int maskX, int maskZ)
 {
@@ -254,8 +254,8 @@ __device__ __forceinline__ void cursor_set(ColumnCursor &c, const DDA &d, const 
 	c.posStepX = d.sx * 65536;
 	c.posStepZ = d.sz;
 	c.rec = level.recordsOff + record_offset((d.px & maskX) >> level.shift, (d.pz & maskZ) >> level.shift, level.rowShift); // clamped into the table
-	c.recStepX = (d.sx >> level.shift) * (32 << level.rowShift); // (sx = +- voxel size, or 0 for a ray that never steps along x)
-	c.recStepZ = (d.sz >> level.shift) * 32;
+	c.recStepX = (d.sx >> level.shift) * (16 << level.rowShift); // (sx = +- voxel size, or 0 for a ray that never steps along x)
+	c.recStepZ = (d.sz >> level.shift) * 16;
 }
 
 __device__ __forceinline__ bool dda_step(DDA &d, float farClip) // :135-150
@@ -538,19 +538,27 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 
 	// The column being processed ("cur") and the values of the DDA / LOD state that belong to it; `ray` itself
 	// already stands on the NEXT column, whose 32-byte record is in flight while this one is processed.
-	uint4 header, queue;              // record of the current column: header + its first two solid runs in walk order
-	uint4 headerB, queueB;            // ... and of the next one (the column loop alternates between the two pairs: no copies at the end of a step)
+	uint4 rec;                        // 16-byte record of the current column (cvx_device.h)
+	uint4 recB;                       // ... and of the next one (the column loop alternates between the two: no copy at the end of a step)
 	float curDistLast, curDistNext;   // ray.IntersectionDistances of the current column
 	unsigned int consumed = 0u;       // counting variant: elements the reference's walk has dereferenced in this column
 	float worldBoundsMin, worldBoundsMax;
 
 	// Clip, element walk and pixel writes of ExecuteRay (:289-611) for the current column;
 	// false = the ray is finished (every such exit is WriteSkybox).
-	auto drawColumn = [&](const uint4 &header, const uint4 &queue) -> bool {
-		const int solidCount = (int)(header.y & 0xFFFFu);
+	auto drawColumn = [&](const uint4 &rec, uint32_t recAddr) -> bool {
+		(void)recAddr;
+		// codes 1 .. 3: the record holds the column's solid runs; code 0 (of a column that is not empty): they live in its block of the run list (cvx_device.h)
+		const bool listed = rec.x < 0x40000000u;
+		const int solidCount = listed ? (int)rec.w : (int)(rec.x >> 30);
 		CVX_BEGIN();
 		if (COUNT) { consumed = 0u; }
-		const uint32_t columnRunsOff = L.runsOff + header.w * 8u; // solid run j >= 2 (top-down numbering) lives at entry j - 2
+		const uint32_t columnRunsOff = L.runsOff + rec.z * 8u; // solid run j (top-down numbering) of a listed column lives at entry j of its block (only listed lanes use it)
+		// the first two runs of a listed column: requested here, used after the clip
+		uint4 listHead = uint4{ 0u, 0u, 0u, 0u };
+		if (CVX_RARE(listed)) { listHead = ld4(arena, columnRunsOff); }
+		uint2 countInfo = uint2{ 0u, 0u }; // counting build: {RunCount | elementIndex of run 0 << 16, elementIndex of run 1 | elementIndex of run 2 << 16}
+		if (COUNT) { countInfo = ld2(arena, L.countsOff + ((recAddr - L.recordsOff) >> 1)); }
 		// :289-293
 		const f3 camSpaceMinLast = f3_madd(planeStartBottom, planeDir, curDistLast);
 		const f3 camSpaceMinNext = f3_madd(planeStartBottom, planeDir, curDistNext);
@@ -654,7 +662,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		// bounds the reference accumulates are exactly these integers), so only solid runs are iterated here.
 		float elementBoundsMin, elementBoundsMax;
 		int solidIndex = 0;
-		const uint32_t worldColumnColorsOff = L.elementsOff + header.x * 4u; // ColorPointer, World.cs:185
+		const uint32_t worldColumnColorsOff = L.elementsOff + (rec.x & 0x3FFFFFFFu) * 4u; // ColorPointer, World.cs:185
 
 		// Rendering build: which solid runs the walk below would project is decided without walking.  A run is projected iff it is
 		// neither entirely above worldBoundsMax (:461-467) nor entirely below worldBoundsMin (:468-475) -- the reference's early
@@ -672,10 +680,23 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		};
 		// RLEElement.Length of that run: its height in voxels of this LOD
 		auto runLength = [&](uint32_t w0) -> int { return (int)(((w0 >> 16) + 1u - (w0 & 0xFFFFu)) >> lod); };
+		// spans and ColorsIndex of the column's first two solid runs.  A record with its runs (cvx_device.h): run 0 = [w.lo, worldMax], run 1 = [z.lo, w.hi + 1],
+		// ColorsIndex = the lengths of the solid runs above (run 0: 0, run 1: Length of run 0); a listed column brings all of that in its block of the run list.
+		float b0 = 0.f, t0 = 0.f, b1 = 0.f, t1 = 0.f;
+		const int length0 = (int)((rec.y >> 16) - (rec.w & 0xFFFFu)) >> lod; // RLEElement.Length of run 0
+		uint32_t colorsIndex0 = 0u, colorsIndex1 = (uint32_t)length0;
 		if (!COUNT) {
-			float b0, t0, b1, t1;
-			runSpan(queue.x, b0, t0);
-			runSpan(queue.z, b1, t1);
+			b0 = (float)(rec.w & 0xFFFFu);
+			t0 = (float)(rec.y >> 16);
+			b1 = (float)(rec.z & 0xFFFFu);
+			t1 = (float)(rec.w >> 16) + 1.0f;
+			if (CVX_RARE(listed)) {
+				runSpan(listHead.x, b0, t0);
+				runSpan(listHead.z, b1, t1);
+				colorsIndex0 = listHead.y & 0xFFFFu;
+				colorsIndex1 = listHead.w & 0xFFFFu;
+				if (solidCount < 1) { b0 = __builtin_inff(); } // a column of air runs only (RunCount > 0, nothing solid): nothing to project
+			}
 			const bool in0 = ((int)!(b0 > worldBoundsMax) & (int)!(t0 < worldBoundsMin)) != 0, in1 = ((int)(solidCount > 1) & (int)!(b1 > worldBoundsMax) & (int)!(t1 < worldBoundsMin)) != 0;
 			vis0 = !windowClosed && in0; // (a column that is drawn has at least one solid run)
 			vis1 = !windowClosed && in1;
@@ -697,7 +718,9 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			// runs beyond the record: rare, so the scan sits behind one branch (bottom-up they come first, top-down last)
 			auto scanOverflow = [&]() {
 				while (DIR > 0 ? ovNext < solidCount : ovNext >= 2) {
-					const uint2 run = ld2(arena, columnRunsOff + (uint32_t)(ovNext - 2) * 8u);
+					// (a record with three runs: run 2 = [worldMin, z.hi + 1], its ColorsIndex = Length of run 0 + Length of run 1; no memory access)
+					uint2 run = uint2{ (rec.y & 0xFFFFu) | (rec.z & 0xFFFF0000u), (uint32_t)(length0 + ((int)((rec.w >> 16) + 1u - (rec.z & 0xFFFFu)) >> lod)) };
+					if (CVX_RARE(listed)) { run = ld2(arena, columnRunsOff + (uint32_t)ovNext * 8u); }
 					ovNext += DIR > 0 ? 1 : -1;
 					runSpan(run.x, elementBoundsMin, elementBoundsMax);
 					if (!(elementBoundsMin > worldBoundsMax) && !(elementBoundsMax < worldBoundsMin)) {
@@ -718,18 +741,17 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 					const bool take0 = ((int)free & (int)(DIR > 0 ? vis0 : (vis0 && !vis1))) != 0;
 					const bool take1 = ((int)free & (int)(DIR > 0 ? (vis1 && !vis0) : vis1)) != 0;
 					const bool take = ((int)take0 | (int)take1) != 0;
-					const uint32_t w0 = take0 ? queue.x : queue.z;
-					const uint32_t w1 = take0 ? queue.y : queue.w;
-					float spanMin, spanMax;
-					runSpan(w0, spanMin, spanMax);
+					const uint32_t w1 = take0 ? colorsIndex0 : colorsIndex1;
+					const float spanMin = take0 ? b0 : b1, spanMax = take0 ? t0 : t1;
+					const int spanLength = (int)(spanMax - spanMin) >> lod; // RLEElement.Length: integers below 2^17, the difference is exact
 					if (DIR > 0) { // (nothing found yet: a lane that takes nothing here either scans on below or leaves the loop)
-						elementLength = runLength(w0);
-						elementColorsIndex = (int)(w1 & 0xFFFFu);
+						elementLength = spanLength;
+						elementColorsIndex = (int)w1;
 						elementBoundsMin = spanMin;
 						elementBoundsMax = spanMax;
 					} else {
-						elementLength = take ? runLength(w0) : elementLength;
-						elementColorsIndex = take ? (int)(w1 & 0xFFFFu) : elementColorsIndex;
+						elementLength = take ? spanLength : elementLength;
+						elementColorsIndex = take ? (int)w1 : elementColorsIndex;
 						elementBoundsMin = take ? spanMin : elementBoundsMin;
 						elementBoundsMax = take ? spanMax : elementBoundsMax;
 					}
@@ -743,19 +765,23 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 				// the walk's k-th solid run is run k of the record's top-down list, or run solidCount - 1 - k for the bottom-up walk
 				const int j = DIR > 0 ? solidIndex : solidCount - 1 - solidIndex;
 				uint32_t w0, w1;
-				if (CVX_USUAL(j < 2)) {
-					const bool odd = j != 0;
-					w0 = odd ? queue.z : queue.x;
-					w1 = odd ? queue.w : queue.y;
-				} else { // 3-8 % of the columns have more than two solid runs: fetched when the walk gets there (memory waits are < 1 % of wave time)
-					const uint2 run = ld2(arena, columnRunsOff + (uint32_t)(j - 2) * 8u);
+				if (CVX_USUAL(!listed)) {
+					// (the record's runs as the run list would hold them: span word {bottomY | (topY - 1) << 16}, colorsIndex | elementIndex << 16)
+					const uint32_t top0 = rec.y - 0x10000u;
+					const uint32_t p0 = (rec.w & 0xFFFFu) | (top0 & 0xFFFF0000u), p1 = (rec.z & 0xFFFFu) | (rec.w & 0xFFFF0000u), p2 = (rec.y & 0xFFFFu) | (rec.z & 0xFFFF0000u);
+					const uint32_t l0 = (uint32_t)runLength(p0), l1 = (uint32_t)runLength(p1);
+					const uint32_t c0 = countInfo.x & 0xFFFF0000u, c1 = l0 | (countInfo.y << 16), c2 = (l0 + l1) | (countInfo.y & 0xFFFF0000u);
+					w0 = j == 0 ? p0 : (j == 1 ? p1 : p2);
+					w1 = j == 0 ? c0 : (j == 1 ? c1 : c2);
+				} else { // a listed column: fetched when the walk gets there
+					const uint2 run = ld2(arena, columnRunsOff + (uint32_t)j * 8u);
 					w0 = run.x;
 					w1 = run.y;
 				}
 				solidIndex++;
 				elementLength = runLength(w0);
 				elementColorsIndex = (int)(w1 & 0xFFFFu);
-				if (COUNT) { consumed = DIR > 0 ? (w1 >> 16) : (header.z >> 16) + 1u - (w1 >> 16); } // position among all elements in walk order
+				if (COUNT) { consumed = DIR > 0 ? (w1 >> 16) : (countInfo.x & 0xFFFFu) + 1u - (w1 >> 16); } // position among all elements in walk order
 				// The run's world-space span.  Top-down the reference accumulates it from worldMaxY (:429-431,449-451), bottom-up from 0
 				// (:433-435,453-455): integer sums either way, and the runs of a column add up to its height, so both are these.
 				runSpan(w0, elementBoundsMin, elementBoundsMax);
@@ -770,7 +796,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			}
 			CVX_END(3);
 			if (COUNT ? !found : CVX_RARE(!found)) { // (rendering build: only a lane that has nothing visible left in the record)
-				if (COUNT && solidIndex == solidCount) { consumed = (header.z >> 16) + 1u; } // walked on to the end guard
+				if (COUNT && solidIndex == solidCount) { consumed = (countInfo.x & 0xFFFFu) + 1u; } // walked on to the end guard
 				if (COUNT) { break; }
 				if (DIR > 0) { // top-down the runs beyond the record come last (here, behind the same rare branch)
 					scanOverflow();
@@ -1015,8 +1041,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 	ColumnCursor cur;
 	cursor_set(cur, ray, L, maskX, maskZ);
 	const int outsideBits = ~((maskX << 16) | maskZ); // bits of a cursor position that are set only outside the world
-	header = ld4(arena, cur.rec);
-	queue = ld4(arena, cur.rec + 16u);
+	rec = ld4(arena, cur.rec);
 
 	// ONE way out of the column loop (`alive`): every early `return` out of a divergent loop costs the structuriser a flag that is
 	// merged at every join on the way out.
@@ -1044,8 +1069,8 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		return m_min(m_min(m_min(farClip, lodMax), edgeDistance()), checkpoint);
 	};
 	float stopDist = stopDistance();
-	// one column step: `header` / `queue` = the column to process (already fetched), `nextHeader` / `nextQueue` receive the look-ahead
-	auto columnStep = [&](const uint4 &header, const uint4 &queue, uint4 &nextHeader, uint4 &nextQueue, auto guardTag) {
+	// one column step: `rec` = the record of the column to process (already fetched), `nextRec` receives the look-ahead
+	auto columnStep = [&](const uint4 &rec, uint4 &nextRec, auto guardTag) {
 		constexpr bool GUARD = decltype(guardTag)::value;
 		CVX_BEGIN();
 		CVX_WAITPROBE(9);
@@ -1057,12 +1082,11 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		// `stopDist` = min(far clip, LOD distance of this level): ONE compare per step serves both (:613 / :273 and :237-243).  A ray that reaches it
 		// leaves the column loop after this column; below the loop it either ends (far clip) or changes level and comes back.  (The record fetched here
 		// for the next column is then the old level's: fetched again after the switch -- twice per ray.)
+		const uint32_t recAddr = cur.rec; // (where `rec` came from: the counting build finds the column's entry of the counts table with it)
 		const bool stopReached = dda_step_cursor(ray, cur, stopDist);
 		// (the fetch is done for every lane, also one that stops after this column: its state is dead, and an unconditional load from
 		// inside the arena is cheaper than branching around it)
-		const uint32_t rec = cur.rec;
-		nextHeader = ld4(arena, rec);
-		nextQueue = ld4(arena, rec + 16u);
+		nextRec = ld4(arena, cur.rec);
 
 		// ---- the current column, exactly as the reference processes it
 		if (COUNT) {
@@ -1075,9 +1099,10 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			worldBoundsMin = 0.0f;
 			worldBoundsMax = worldMaxY;
 			{ // :251-256 (RunCount > 0: not an empty column) and :261-281, straight-line: the tests as flags (`&` / `|`: no nested divergent regions), the bounds as selects
-				const bool cull = ((int)((header.z >> 16) != 0u) & (int)(frustumDirMaxWorld != CVX_FLOAT_EPSILON)) != 0;
-				const float columnWorldMin = (float)(header.y >> 16);
-				const float columnWorldMax = (float)(header.z & 0xFFFFu);
+				const bool nonEmpty = rec.x != 0u; // RunCount > 0 (the empty column's record is all zeros, cvx_device.h)
+				const bool cull = ((int)nonEmpty & (int)(frustumDirMaxWorld != CVX_FLOAT_EPSILON)) != 0;
+				const float columnWorldMin = (float)(rec.y & 0xFFFFu);
+				const float columnWorldMax = (float)(rec.y >> 16);
 				// :264-269: the upper bound at the farther distance when the direction rises, at the nearer one otherwise (the lower bound likewise) -- written
 				// as the larger / smaller of the two products (curDistNext >= curDistLast >= 0 and rounding is monotone, so the product the reference
 				// selects IS the larger / smaller one): a max / min instead of a compare + select, same value
@@ -1087,13 +1112,13 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 				const bool noOverlap = ((int)cull & ((int)(columnWorldMin > newMax) | (int)(columnWorldMax < newMin))) != 0; // this column does not overlap the writable world bounds
 				const bool narrowed = ((int)cull & (int)!leftWorld & (int)!noOverlap) != 0;
 				alive = !leftWorld;
-				draw = ((int)((header.z >> 16) != 0u) & (int)!leftWorld & (int)!noOverlap) != 0;
+				draw = ((int)nonEmpty & (int)!leftWorld & (int)!noOverlap) != 0;
 				worldBoundsMin = narrowed ? newMin : worldBoundsMin;
 				worldBoundsMax = narrowed ? newMax : worldBoundsMax;
 			}
 			CVX_END(1);
 			if (draw) {
-				alive = drawColumn(header, queue);
+				alive = drawColumn(rec, recAddr);
 				if (COUNT) { cnt.E += consumed; }
 				// Every vector-memory operation of the drawn column is complete from here on.  Without this the compiler does not know what the pixel loops left in
 				// flight (a colour load whose pixel loop never ran, stores) when the paths of a drawn and a skipped column join below, and drains the queue
@@ -1119,9 +1144,9 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 	// current one" at the end of a step (8 v_mov per step); the code of a step exists twice for it.
 	for (;;) {
 		while (go) {
-			columnStep(header, queue, headerB, queueB, std::true_type{});
+			columnStep(rec, recB, std::true_type{});
 			if (go) {
-				columnStep(headerB, queueB, header, queue, std::false_type{});
+				columnStep(recB, rec, std::false_type{});
 			}
 		}
 		// NextLOD (:237-243) for the column the ray stands on, if that is why it left the loop: alive, at or beyond this level's LOD distance, not
@@ -1136,8 +1161,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			const float fresh = nearEdge ? -__builtin_inff() : stopDistance();
 			nearEdge = !(fresh > ray.distLast);
 			stopDist = nearEdge ? -__builtin_inff() : fresh;
-			header = ld4(arena, cur.rec);
-			queue = ld4(arena, cur.rec + 16u);
+			rec = ld4(arena, cur.rec);
 			go = true;
 			continue;
 		}
@@ -1153,8 +1177,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		{ const float next_ = F.lod[min(lod, 5)]; lodMax = lod < 5 ? next_ : __builtin_inff(); }
 		cursor_set(cur, ray, L, maskX, maskZ);
 		stopDist = nearEdge ? -__builtin_inff() : stopDistance();
-		header = ld4(arena, cur.rec);
-		queue = ld4(arena, cur.rec + 16u);
+		rec = ld4(arena, cur.rec);
 		go = true;
 	}
 }

@@ -81,13 +81,47 @@ int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byt
 	const RefHeader *src = static_cast<const RefHeader *>(storage);
 	const uint32_t *elements = reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(storage) + (size_t)columnCount * 12);
 
-	// Validate every column (so that nothing the kernel dereferences can leave the pool) and build the table of 32-byte
-	// solid-run records (row-major) plus the overflow list (cvx_device.h).  The data goes to the device with the next draw.
+	// Validate every column (so that nothing the kernel dereferences can leave the pool) and build the table of 16-byte
+	// column records (row-major), the run list and the counting build's table (cvx_device.h).  The data goes to the device with the next draw.
 	const int maxY = dimY >> lod;
 	int rowShift = 0;
 	while (((int64_t)1 << rowShift) < usedZ) { rowShift++; }
 	const size_t recordCount = (size_t)usedX << rowShift;
-	size_t overflowEntries = 2; // never empty; the kernel may read two entries at any overflowBase
+	if (elementCount >= ((int64_t)1 << 30)) {
+		return Fail(ctx, CVX_ERR_CAPACITY, "LOD %d: an element pool of %lld entries (the records address 2^30)", lod, (long long)elementCount);
+	}
+	// pass 1: validation, and the size of the run list (a block per column whose record cannot hold its runs: an even number of entries)
+	struct Shape {
+		uint32_t solid;                  // solid runs
+		uint32_t bottom[3], top[3];      // spans of the first three, LOD-0 voxels
+		uint32_t position[3];            // 1-based position among all elements, top-down
+		bool derived;                    // every ColorsIndex is the sum of the lengths of the solid runs above it (what the reference's builder emits)
+	};
+	const auto shapeOf = [&](const RefHeader &h) {
+		Shape sh{};
+		sh.derived = true;
+		uint32_t start = 0, colours = 0;
+		for (int r = 0; r < h.runCount; r++) { // top-down
+			const uint32_t raw = elements[h.storageOffset + 1 + r];
+			const uint32_t length = raw >> 16;
+			if ((int16_t)(raw & 0xFFFFu) >= 0) {
+				// the run's span in LOD-0 voxels: [bottomY, topY] with topY = dimY - (start << lod) (<= 65536)
+				const uint32_t topY = (uint32_t)dimY - (start << lod), bottomY = topY - (length << lod);
+				if (sh.solid < 3) { sh.bottom[sh.solid] = bottomY; sh.top[sh.solid] = topY; sh.position[sh.solid] = (uint32_t)(r + 1); }
+				if ((raw & 0xFFFFu) != colours) { sh.derived = false; }
+				colours += length;
+				sh.solid++;
+			}
+			start += length;
+		}
+		return sh;
+	};
+	// 1 .. 3: the record holds the column's runs (cvx_device.h); 0: they live in the run list
+	const auto codeOf = [](const RefHeader &h, const Shape &sh) -> uint32_t {
+		if (sh.solid >= 1 && sh.solid <= 3 && sh.derived && h.worldMax == sh.top[0] && h.worldMin == sh.bottom[sh.solid - 1]) { return sh.solid; }
+		return 0u;
+	};
+	size_t listEntries = 0;
 	for (int64_t i = 0; i < usedColumns; i++) {
 		const RefHeader &h = src[i];
 		if (h.runCount == 0) {
@@ -98,14 +132,15 @@ int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byt
 		if (rc != CVX_OK) {
 			return rc;
 		}
-		if (solid > 2) {
-			overflowEntries += solid - 2;
+		if (codeOf(h, shapeOf(h)) == 0u) {
+			listEntries += (solid + 1) & ~(size_t)1;
 		}
 	}
 	cvx_context::HostLevel &H = ctx->hostLevel[lod];
-	H.records.assign(recordCount * 2, uint4{ 0u, 0u, 0u, 0u });
-	H.runs.assign(overflowEntries + 2, uint2{ 0u, 0u });
-	size_t overflowCursor = 0;
+	H.records.assign(recordCount, uint4{ 0u, 0u, 0u, 0u });
+	H.counts.assign(recordCount, uint2{ 0u, 0u });
+	H.runs.assign(listEntries + 4, uint2{ 0u, 0u }); // never empty; the kernel may read two entries at any block
+	size_t listCursor = 0;
 	for (int64_t cx = 0; cx < usedX; cx++) {
 		for (int64_t cz = 0; cz < usedZ; cz++) {
 			const int64_t i = cx * usedZ + cz; // World.GetIndexKnownInBounds, World.cs:145-149
@@ -115,28 +150,34 @@ int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byt
 			}
 			const int64_t off = h.storageOffset;
 			const int n = h.runCount;
-			uint4 *rec = H.records.data() + 2 * (((size_t)cx << rowShift) + (size_t)cz);
-			uint32_t start = 0, solid = 0;
-			const size_t listBase = overflowCursor;
-			uint2 first[2] = { uint2{ 0u, 0u }, uint2{ 0u, 0u } };
-			for (int r = 0; r < n; r++) { // top-down
-				const uint32_t raw = elements[off + 1 + r];
-				const uint32_t length = raw >> 16;
-				if ((int16_t)(raw & 0xFFFFu) >= 0) {
-					// the run's span in LOD-0 voxels, ready for the kernel: [bottomY, topY] with topY = dimY - (start << lod) (<= 65536: stored minus one)
-					const uint32_t topY = (uint32_t)dimY - (start << lod), bottomY = topY - (length << lod);
-					const uint2 run = uint2{ bottomY | ((topY - 1u) << 16), (raw & 0xFFFFu) | ((uint32_t)(r + 1) << 16) };
-					if (solid < 2) {
-						first[solid] = run;
-					} else {
-						H.runs[overflowCursor++] = run;
+			const size_t at = ((size_t)cx << rowShift) + (size_t)cz;
+			const Shape sh = shapeOf(h);
+			const uint32_t code = codeOf(h, sh);
+			const uint32_t colorsBase = (uint32_t)(off + n + 2); // (>= 3: a listed column's x is never 0, the empty column's always)
+			const uint32_t bounds = (uint32_t)h.worldMin | ((uint32_t)h.worldMax << 16);
+			uint32_t z = 0, w = 0;
+			if (code == 0u) {
+				const size_t block = listCursor;
+				uint32_t start = 0;
+				for (int r = 0; r < n; r++) { // top-down
+					const uint32_t raw = elements[off + 1 + r];
+					const uint32_t length = raw >> 16;
+					if ((int16_t)(raw & 0xFFFFu) >= 0) {
+						const uint32_t topY = (uint32_t)dimY - (start << lod), bottomY = topY - (length << lod);
+						H.runs[listCursor++] = uint2{ bottomY | ((topY - 1u) << 16), (raw & 0xFFFFu) | ((uint32_t)(r + 1) << 16) };
 					}
-					solid++;
+					start += length;
 				}
-				start += length;
+				listCursor = (listCursor + 1) & ~(size_t)1;
+				z = (uint32_t)block;
+				w = sh.solid;
+			} else {
+				// run 0 = [w.lo, worldMax], run 1 = [z.lo, w.hi + 1], run 2 = [worldMin, z.hi + 1]; the last run's foot is worldMin
+				w = (code >= 2u) ? (sh.bottom[0] | ((sh.top[1] - 1u) << 16)) : bounds;
+				z = (code == 3u) ? (sh.bottom[1] | ((sh.top[2] - 1u) << 16)) : (uint32_t)h.worldMin;
 			}
-			rec[0] = uint4{ (uint32_t)(off + n + 2), solid | ((uint32_t)h.worldMin << 16), (uint32_t)h.worldMax | ((uint32_t)n << 16), (uint32_t)listBase };
-			rec[1] = uint4{ first[0].x, first[0].y, first[1].x, first[1].y };
+			H.records[at] = uint4{ (code << 30) | colorsBase, bounds, z, w };
+			H.counts[at] = uint2{ (uint32_t)n | (sh.position[0] << 16), sh.position[1] | (sh.position[2] << 16) };
 		}
 	}
 	const size_t kPoolPad = 4; // zeroed guard entries around the pool
@@ -146,6 +187,7 @@ int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byt
 	}
 	H.recordsBytes = H.records.size() * sizeof(uint4);
 	H.runsBytes = H.runs.size() * sizeof(uint2);
+	H.countsBytes = H.counts.size() * sizeof(uint2);
 	H.elementsBytes = H.elements.size() * sizeof(uint32_t);
 	H.rowShift = rowShift;
 	H.pending = true;

@@ -135,6 +135,8 @@ def main():
 
     if args.latency > 0:
         lat = {b[0]: [] for b in builds}
+        for b in builds[len(names):]:  # (closed through their OWN library: a context collected later would be destroyed by whichever build is current)
+            use(b).close()
         builds = builds[:len(names)]
         frames = [frame_for(i * 5) for i in range(args.latency)]
         for r in range(3):
