@@ -550,14 +550,12 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 		(void)recAddr;
 		// codes 1 .. 3: the record holds the column's solid runs; code 0 (of a column that is not empty): they live in its block of the run list (cvx_device.h)
 		const bool listed = rec.x < 0x40000000u;
-		const int solidCount = listed ? (int)rec.w : (int)(rec.x >> 30);
+		int solidCount = (int)(rec.x >> 30);
+		if (COUNT) { solidCount = listed ? (int)rec.w : solidCount; }
 		CVX_BEGIN();
 		if (COUNT) { consumed = 0u; }
 		const uint32_t columnRunsOff = L.runsOff + rec.z * 8u; // solid run j (top-down numbering) of a listed column lives at entry j of its block (only listed lanes use it)
-		// the first two runs of a listed column: requested here, used after the clip
-		uint4 listHead = uint4{ 0u, 0u, 0u, 0u };
-		if (CVX_RARE(listed)) { listHead = ld4(arena, columnRunsOff); }
-		uint2 countInfo = uint2{ 0u, 0u }; // counting build: {RunCount | elementIndex of run 0 << 16, elementIndex of run 1 | elementIndex of run 2 << 16}
+uint2 countInfo = uint2{ 0u, 0u }; // counting build: {RunCount | elementIndex of run 0 << 16, elementIndex of run 1 | elementIndex of run 2 << 16}
 		if (COUNT) { countInfo = ld2(arena, L.countsOff + ((recAddr - L.recordsOff) >> 1)); }
 		// :289-293
 		const f3 camSpaceMinLast = f3_madd(planeStartBottom, planeDir, curDistLast);
@@ -690,7 +688,9 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 			t0 = (float)(rec.y >> 16);
 			b1 = (float)(rec.z & 0xFFFFu);
 			t1 = (float)(rec.w >> 16) + 1.0f;
-			if (CVX_RARE(listed)) {
+			if (CVX_RARE(listed)) { // (a handful of columns per thousand: their first two runs are fetched where they are needed)
+				const uint4 listHead = ld4(arena, columnRunsOff);
+				solidCount = (int)rec.w;
 				runSpan(listHead.x, b0, t0);
 				runSpan(listHead.z, b1, t1);
 				colorsIndex0 = listHead.y & 0xFFFFu;
