@@ -46,7 +46,7 @@ struct cvx_context {
 		std::vector<uint4> records;     // 1 per column, row-major (cvx_device.h); empty once the level lives in the arena
 		std::vector<uint2> runs;        // run list: every solid run of the columns whose record cannot hold them
 		std::vector<uint2> counts;      // per column, what only the counting build reads
-		std::vector<uint32_t> elements; // padded with zeroed guard entries on both sides
+		std::vector<uint32_t> elements; // the columns' colours, densely packed in table order, padded with zeroed guard entries on both sides
 		size_t recordsBytes = 0, runsBytes = 0, countsBytes = 0, elementsBytes = 0;
 		bool pending = false;           // host vectors hold data that is not in the arena yet
 		int rowShift = 0;
@@ -119,8 +119,8 @@ inline bool IsPow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 // One column of a world blob in the reference's layout (World.cs:161-209): element range inside the pool, both guards
 // present, positive run lengths that fit the column height, colours inside the pool.  Everything the kernels dereference
-// later is covered here.  *solidRuns receives the number of solid runs.
-int ValidateColumn(cvx_context *ctx, int64_t i, const RefHeader &h, const uint32_t *elements, int64_t elementCount, int maxY, size_t *solidRuns);
+// later is covered here.  *solidRuns receives the number of solid runs, *colourCount (optional) the number of colours the runs address.
+int ValidateColumn(cvx_context *ctx, int64_t i, const RefHeader &h, const uint32_t *elements, int64_t elementCount, int maxY, size_t *solidRuns, int64_t *colourCount = nullptr);
 
 } // namespace cvxi
 

@@ -2,8 +2,8 @@
 //
 // World: ONE arena for all six LODs.  Per LOD a row-major table of 16-byte column records (World.GetIndexKnownInBounds' x-major order, World.cs:
 // 145-149), built on upload from the reference's 12-byte headers (World.cs:161-169),
-// a run list for the few columns whose record cannot hold their runs, and the element pool in the reference's own
-// order [guard][run 0..n-1][guard][colour 0..s-1] (World.cs:163-165), from which the kernel reads the colours.  Everything
+// a run list for the few columns whose record cannot hold their runs, and the columns' colours, densely packed in table order (the reference's
+// pool interleaves them with the RLE elements, [guard][run 0..n-1][guard][colour 0..s-1], World.cs:163-165: the kernel never reads those).  Everything
 // is addressed with 32-bit byte offsets from the arena base (one scalar register pair for the whole wave; the arena is
 // limited to 4 GiB).
 //
@@ -28,7 +28,7 @@ struct DevWorldLevel {
 	// [bottomY, topY] in LOD-0 voxels (topY = dimY - (voxels of this LOD above the run << lod); upload checks that the runs of a column add
 	// up to the column height -- the reference's builder always emits such columns, WordBuilder.cs:232-258 -- so the same numbers are what
 	// the bottom-up walk accumulates).
-	//   x = code << 30 | colorsBase      colorsBase = element index (inside this level's pool) of the column's first colour (RLEColumn.ColorPointer, World.cs:185; >= 3)
+	//   x = code << 30 | colorsBase      colorsBase = index (inside this level's colour array) of the column's first colour (RLEColumn.ColorPointer, World.cs:185; >= 4)
 	//   y = worldMin | worldMax << 16    RLEColumn.WorldMin / WorldMax as the blob has them (World.cs:161-169): what the cull of every column step reads
 	//   x == 0: RunCount == 0 (the empty column, all four words 0)
 	//   code 1 .. 3 = the number of solid runs, for a column the builder's invariants hold for -- the top run ends at worldMax, the lowest one stands on
@@ -48,7 +48,7 @@ struct DevWorldLevel {
 	// record one step outside.
 	uint32_t recordsOff;  // byte offsets from DevWorld::arena
 	uint32_t runsOff;     // run list: uint2 per solid run of the listed columns
-	uint32_t elementsOff; // the reference's element pool (RLEElement / ColorARGB32); the kernel reads colours only
+	uint32_t elementsOff; // the columns' colours (ColorARGB32), densely packed in table order behind four zeroed guard entries
 	int32_t shift;        // lod
 	int32_t rowShift;     // log2 of the records per row (columns of this level along z)
 	uint32_t countsOff;   // uint2 per column, indexed like the records

@@ -342,7 +342,7 @@ int SyncWorld(cvx_context *ctx)
 				e = hipMemcpy(arena + recordsAt[i], ctx->arena + old.recordsOff, H.recordsBytes, hipMemcpyDeviceToDevice);
 				if (e == hipSuccess) { e = hipMemcpy(arena + runsAt[i], ctx->arena + old.runsOff, H.runsBytes, hipMemcpyDeviceToDevice); }
 				if (e == hipSuccess) { e = hipMemcpy(arena + countsAt[i], ctx->arena + old.countsOff, H.countsBytes, hipMemcpyDeviceToDevice); }
-				if (e == hipSuccess) { e = hipMemcpy(arena + elementsAt[i], ctx->arena + old.elementsOff - 16, H.elementsBytes, hipMemcpyDeviceToDevice); }
+				if (e == hipSuccess) { e = hipMemcpy(arena + elementsAt[i], ctx->arena + old.elementsOff, H.elementsBytes, hipMemcpyDeviceToDevice); }
 			}
 		}
 		if (e != hipSuccess) {
@@ -359,7 +359,7 @@ int SyncWorld(cvx_context *ctx)
 			DevWorldLevel &L = next.level[i];
 			L.recordsOff = (uint32_t)recordsAt[i];
 			L.runsOff = (uint32_t)runsAt[i];
-			L.elementsOff = (uint32_t)(elementsAt[i] + 16); // past the leading guard entries (kPoolPad * 4 bytes)
+			L.elementsOff = (uint32_t)elementsAt[i]; // (colour indices count from the start of the padded array)
 			L.shift = i;
 			L.rowShift = H.rowShift;
 			L.countsOff = (uint32_t)countsAt[i];

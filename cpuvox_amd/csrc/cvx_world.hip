@@ -20,8 +20,8 @@ namespace cvxi {
 
 // One column of a world blob in the reference's layout (World.cs:161-209): element range inside the pool, both
 // guards present, positive run lengths that fit the column height, colours inside the pool.  Everything the kernels
-// dereference later is covered here.  *solidRuns receives the number of solid runs.
-int ValidateColumn(cvx_context *ctx, int64_t i, const RefHeader &h, const uint32_t *elements, int64_t elementCount, int maxY, size_t *solidRuns)
+// dereference later is covered here.  *solidRuns receives the number of solid runs, *colourCount (optional) the number of colours the runs address.
+int ValidateColumn(cvx_context *ctx, int64_t i, const RefHeader &h, const uint32_t *elements, int64_t elementCount, int maxY, size_t *solidRuns, int64_t *colourCount)
 {
 	const int64_t off = h.storageOffset;
 	if (off < 0 || off + h.runCount + 2 > elementCount) {
@@ -51,6 +51,7 @@ int ValidateColumn(cvx_context *ctx, int64_t i, const RefHeader &h, const uint32
 		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "column %lld: runs do not add up to the column height or colours exceed the pool", (long long)i);
 	}
 	*solidRuns = solid;
+	if (colourCount) { *colourCount = colours; }
 	return CVX_OK;
 }
 
@@ -87,8 +88,8 @@ int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byt
 	int rowShift = 0;
 	while (((int64_t)1 << rowShift) < usedZ) { rowShift++; }
 	const size_t recordCount = (size_t)usedX << rowShift;
-	if (elementCount >= ((int64_t)1 << 30)) {
-		return Fail(ctx, CVX_ERR_CAPACITY, "LOD %d: an element pool of %lld entries (the records address 2^30)", lod, (long long)elementCount);
+	if (elementCount >= ((int64_t)1 << 30)) { // (the colours are a subset of the pool)
+		return Fail(ctx, CVX_ERR_CAPACITY, "LOD %d: an element pool of %lld entries (the records address 2^30 colours)", lod, (long long)elementCount);
 	}
 	// pass 1: validation, and the size of the run list (a block per column whose record cannot hold its runs: an even number of entries)
 	struct Shape {
@@ -122,16 +123,21 @@ int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byt
 		return 0u;
 	};
 	size_t listEntries = 0;
+	std::vector<uint32_t> colourCounts((size_t)usedColumns, 0u);
+	int64_t colourTotal = 0; // colours of all columns: the device keeps them densely packed (the reference's pool interleaves them with the RLE elements, which the kernel never reads)
 	for (int64_t i = 0; i < usedColumns; i++) {
 		const RefHeader &h = src[i];
 		if (h.runCount == 0) {
 			continue;
 		}
 		size_t solid = 0;
-		const int rc = ValidateColumn(ctx, i, h, elements, elementCount, maxY, &solid);
+		int64_t colours = 0;
+		const int rc = ValidateColumn(ctx, i, h, elements, elementCount, maxY, &solid, &colours);
 		if (rc != CVX_OK) {
 			return rc;
 		}
+		colourCounts[(size_t)i] = (uint32_t)colours;
+		colourTotal += colours;
 		if (codeOf(h, shapeOf(h)) == 0u) {
 			listEntries += (solid + 1) & ~(size_t)1;
 		}
@@ -140,7 +146,9 @@ int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byt
 	H.records.assign(recordCount, uint4{ 0u, 0u, 0u, 0u });
 	H.counts.assign(recordCount, uint2{ 0u, 0u });
 	H.runs.assign(listEntries + 4, uint2{ 0u, 0u }); // never empty; the kernel may read two entries at any block
-	size_t listCursor = 0;
+	const size_t kPoolPad = 4; // zeroed guard entries around the colours
+	H.elements.assign((size_t)colourTotal + 2 * kPoolPad, 0u);
+	size_t listCursor = 0, colourCursor = kPoolPad;
 	for (int64_t cx = 0; cx < usedX; cx++) {
 		for (int64_t cz = 0; cz < usedZ; cz++) {
 			const int64_t i = cx * usedZ + cz; // World.GetIndexKnownInBounds, World.cs:145-149
@@ -153,7 +161,10 @@ int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byt
 			const size_t at = ((size_t)cx << rowShift) + (size_t)cz;
 			const Shape sh = shapeOf(h);
 			const uint32_t code = codeOf(h, sh);
-			const uint32_t colorsBase = (uint32_t)(off + n + 2); // (>= 3: a listed column's x is never 0, the empty column's always)
+			// RLEColumn.ColorPointer (World.cs:185) in the packed pool (>= 4: a listed column's x is never 0, the empty column's always)
+			const uint32_t colorsBase = (uint32_t)colourCursor;
+			std::memcpy(H.elements.data() + colourCursor, elements + off + n + 2, (size_t)colourCounts[(size_t)i] * 4);
+			colourCursor += colourCounts[(size_t)i];
 			const uint32_t bounds = (uint32_t)h.worldMin | ((uint32_t)h.worldMax << 16);
 			uint32_t z = 0, w = 0;
 			if (code == 0u) {
@@ -179,11 +190,6 @@ int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byt
 			H.records[at] = uint4{ (code << 30) | colorsBase, bounds, z, w };
 			H.counts[at] = uint2{ (uint32_t)n | (sh.position[0] << 16), sh.position[1] | (sh.position[2] << 16) };
 		}
-	}
-	const size_t kPoolPad = 4; // zeroed guard entries around the pool
-	H.elements.assign((size_t)(elementCount > 0 ? elementCount : 0) + 2 * kPoolPad, 0u);
-	if (elementCount > 0) {
-		std::memcpy(H.elements.data() + kPoolPad, elements, (size_t)elementCount * 4);
 	}
 	H.recordsBytes = H.records.size() * sizeof(uint4);
 	H.runsBytes = H.runs.size() * sizeof(uint2);
