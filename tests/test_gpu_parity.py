@@ -526,6 +526,62 @@ def test_run_rich_world_slow_paths(contexts):
     assert directions == {False, True}, "both element iteration directions must be covered"
 
 
+def test_foreign_blob_columns_go_through_the_run_list():
+    """Round 5: a 16-byte device record holds a column's runs only under the invariants of the reference's builder (the top run ends at WorldMax,
+    the lowest stands on WorldMin, every ColorsIndex is the sum of the lengths above it; cvx_device.h); any other column is "listed".  The C ABI
+    accepts every blob the reference's loader would, so here a built world's LOD-0 blob is edited into shapes no builder emits -- header bounds
+    wider than the runs, a second run that shares the first one's colours, columns of air runs only (RunCount > 0, nothing solid) -- and
+    rendered against the oracle, which walks the blob as the reference does: counting and rendering build, both iteration directions."""
+    dims = (64, 128, 64)
+    x, y, z, argb = _random_alpha_world(dims, 21, 3500, 3)
+    base = host.WorldSet.from_voxels(dims, x, y, z, argb, threads=4)
+    blobs = [np.array(base.storage(lod), dtype=np.uint8, copy=True) for lod in range(base.lod_count)]
+    blob = blobs[0]
+    columns = dims[0] * dims[2]
+    header = np.dtype({"names": ["off", "rc", "mn", "mx"], "formats": ["<i4", "<u2", "<u2", "<u2"], "offsets": [0, 4, 6, 8], "itemsize": 12})
+    hdr = blob[:columns * 12].view(header)
+    el = blob[columns * 12:].view(np.dtype([("ci", "<i2"), ("len", "<i2")]))
+    edited = {"bounds": 0, "shared colours": 0, "air only": 0}
+    for c in range(columns):
+        h = hdr[c]
+        if h["rc"] == 0:
+            continue
+        runs = el[h["off"] + 1: h["off"] + 1 + h["rc"]]
+        solid = np.flatnonzero(runs["ci"] >= 0)
+        if c % 5 == 0:
+            hdr[c]["mx"] = min(dims[1], int(h["mx"]) + 2)
+            hdr[c]["mn"] = max(0, int(h["mn"]) - 1)
+            edited["bounds"] += 1
+        elif c % 5 == 1 and solid.size >= 2:
+            runs["ci"][solid[1]] = 0  # (its colours [0, len) lie inside the column's colour array: len1 <= len0 + len1)
+            edited["shared colours"] += 1
+        elif c % 5 == 2:
+            runs["ci"][solid] = -1
+            edited["air only"] += 1
+    assert min(edited.values()) > 50, edited
+    ws = host.WorldSet.from_blobs(dims, blobs)
+    W, H = 320, 200
+    ctx = gpu.Context(0)
+    try:
+        ctx.upload_world(ws)
+        ctx.set_resolution(W, H)
+        directions = set()
+        for pos, eul in (((32.3, 70.0, 5.2), (5.0, 10.0, 0.0)), ((32.3, 140.0, 32.2), (70.0, 30.0, 0.0)), ((10.3, -20.0, 50.2), (-40.0, 120.0, 0.0)),
+                         ((60.3, 64.0, 60.2), (0.0, 225.0, 0.0)), ((32.3, 100.0, 32.2), (-25.0, 300.0, 0.0))):
+            fr = scenes.make_frame(ws, W, H, pos, eul)
+            directions.add(bool(fr.camera.InverseElementIterationDirection))
+            o_td, o_lr, cnt = O.draw_segments(ws, fr, W, H, clear=CLEAR)
+            for counting in (True, False):
+                g_td, g_lr = _render_gpu(ctx, fr, counters=counting)
+                _compare(f"foreign blob pos={pos} eul={eul} counting={counting}", fr, g_td, g_lr, o_td, o_lr)
+                if counting:
+                    gc = ctx.counters()
+                    assert (gc.S, gc.E, gc.C, gc.P, gc.R) == (cnt.S, cnt.E, cnt.C, cnt.P, cnt.R), (gc.as_dict(), cnt.as_dict())
+        assert directions == {False, True}
+    finally:
+        ctx.close()
+
+
 def test_long_world_far_edge_checkpoints(contexts):
     """a ray that makes more than ~9 000 crossings on one axis at one LOD level.  The column loop tests the ray's position
     only beyond a stop distance `tMax + (n - 4) tDelta`; the DDA's own additions drift by ~n^2 2^-24 tDelta, so over 16 384 crossings the three

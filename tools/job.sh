@@ -1,5 +1,4 @@
 #!/bin/bash
-mkdir -p gpurun_out/r05d
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/r05d/gputests3.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/r05d/gputests3.log
-timeout -k 10 600 python3 tools/ab_fast.py "libcpuvox_gpu_base.so libcpuvox_gpu_v2b.so libcpuvox_gpu.so" --contexts 3 --latency 200 > gpurun_out/r05d/ab5.txt 2>&1
-tail -10 gpurun_out/r05d/ab5.txt
+mkdir -p gpurun_out/r05g
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/r05g/gputests.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/r05g/gputests.log
+timeout -k 10 900 python3 tools/soak.py 1000 > gpurun_out/r05g/soak.txt 2>&1; tail -1 gpurun_out/r05g/soak.txt
