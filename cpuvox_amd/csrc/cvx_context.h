@@ -46,7 +46,7 @@ struct cvx_context {
 		std::vector<uint4> records;     // 1 per column, row-major (cvx_device.h); empty once the level lives in the arena
 		std::vector<uint2> runs;        // run list: every solid run of the columns whose record cannot hold them
 		std::vector<uint2> counts;      // per column, what only the counting build reads
-		std::vector<uint32_t> elements; // the columns' colours, densely packed in table order, padded with zeroed guard entries on both sides
+		std::vector<uint32_t> elements; // the columns' colours in blocks of 4 x 8 columns (cvx_device.h), a line of zeros on both sides
 		size_t recordsBytes = 0, runsBytes = 0, countsBytes = 0, elementsBytes = 0;
 		bool pending = false;           // host vectors hold data that is not in the arena yet
 		int rowShift = 0;

@@ -2,7 +2,7 @@
 //
 // World: ONE arena for all six LODs.  Per LOD a row-major table of 16-byte column records (World.GetIndexKnownInBounds' x-major order, World.cs:
 // 145-149), built on upload from the reference's 12-byte headers (World.cs:161-169),
-// a run list for the few columns whose record cannot hold their runs, and the columns' colours, densely packed in table order (the reference's
+// a run list for the few columns whose record cannot hold their runs, and the columns' colours in blocks of 4 x 8 columns (the reference's
 // pool interleaves them with the RLE elements, [guard][run 0..n-1][guard][colour 0..s-1], World.cs:163-165: the kernel never reads those).  Everything
 // is addressed with 32-bit byte offsets from the arena base (one scalar register pair for the whole wave; the arena is
 // limited to 4 GiB).
@@ -16,6 +16,12 @@
 #include <stdint.h>
 
 #define CVX_WAVE 64
+// Colour blocks (see DevWorldLevel::elementsOff): 4 x 8 columns, colour k of a column CVX_COLOR_STRIDE entries behind its colour k - 1
+#ifndef CVX_COLOR_BLOCK_X
+#define CVX_COLOR_BLOCK_X 4
+#define CVX_COLOR_BLOCK_Z 8
+#endif
+#define CVX_COLOR_STRIDE (CVX_COLOR_BLOCK_X * CVX_COLOR_BLOCK_Z)
 #define CVX_SKYBOX_ARGB 0x191919FFu /* ColorARGB32(25,25,25): bytes FF 19 19 19 (DrawSegmentRayJob.cs:702) */
 
 struct DevWorldLevel {
@@ -28,7 +34,7 @@ struct DevWorldLevel {
 	// [bottomY, topY] in LOD-0 voxels (topY = dimY - (voxels of this LOD above the run << lod); upload checks that the runs of a column add
 	// up to the column height -- the reference's builder always emits such columns, WordBuilder.cs:232-258 -- so the same numbers are what
 	// the bottom-up walk accumulates).
-	//   x = code << 30 | colorsBase      colorsBase = index (inside this level's colour array) of the column's first colour (RLEColumn.ColorPointer, World.cs:185; >= 4)
+	//   x = code << 30 | colorsBase      colorsBase = slot (inside this level's colour array) of the column's first colour (RLEColumn.ColorPointer, World.cs:185; >= 32)
 	//   y = worldMin | worldMax << 16    RLEColumn.WorldMin / WorldMax as the blob has them (World.cs:161-169): what the cull of every column step reads
 	//   x == 0: RunCount == 0 (the empty column, all four words 0)
 	//   code 1 .. 3 = the number of solid runs, for a column the builder's invariants hold for -- the top run ends at worldMax, the lowest one stands on
@@ -48,7 +54,11 @@ struct DevWorldLevel {
 	// record one step outside.
 	uint32_t recordsOff;  // byte offsets from DevWorld::arena
 	uint32_t runsOff;     // run list: uint2 per solid run of the listed columns
-	uint32_t elementsOff; // the columns' colours (ColorARGB32), densely packed in table order behind four zeroed guard entries
+	// The columns' colours (ColorARGB32; the reference's pool interleaves them with the RLE elements, which the kernel never reads), in blocks of 4 x 8
+	// columns: colour k of the block's 32 columns fills ONE 128-byte line, colour k of a column lives CVX_COLOR_STRIDE entries behind its colour k - 1,
+	// and a block is as deep as its column with the most colours.  What the rays of a wave read at a step are the first few colours (the top voxels)
+	// of neighbouring columns: one line for all of them, where the column-after-column order spent a line on three columns' full stacks.
+	uint32_t elementsOff;
 	int32_t shift;        // lod
 	int32_t rowShift;     // log2 of the records per row (columns of this level along z)
 	uint32_t countsOff;   // uint2 per column, indexed like the records

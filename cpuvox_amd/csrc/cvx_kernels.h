@@ -537,7 +537,7 @@ __device__ __forceinline__ void trace_ray(const DevFrame &F, const DevSegment &S
 	int guardSteps = dimX + dimZ + 16;
 
 	// The column being processed ("cur") and the values of the DDA / LOD state that belong to it; `ray` itself
-	// already stands on the NEXT column, whose 32-byte record is in flight while this one is processed.
+	// already stands on the NEXT column, whose 16-byte record is in flight while this one is processed.
 	uint4 rec;                        // 16-byte record of the current column (cvx_device.h)
 	uint4 recB;                       // ... and of the next one (the column loop alternates between the two: no copy at the end of a step)
 	float curDistLast, curDistNext;   // ray.IntersectionDistances of the current column
@@ -665,11 +665,11 @@ uint2 countInfo = uint2{ 0u, 0u }; // counting build: {RunCount | elementIndex o
 		// Rendering build: which solid runs the walk below would project is decided without walking.  A run is projected iff it is
 		// neither entirely above worldBoundsMax (:461-467) nor entirely below worldBoundsMin (:468-475) -- the reference's early
 		// `break`s only skip runs that these two tests would skip anyway (the runs of a column are sorted by height), and the
-		// world bounds do not change inside the element loop.  So the two runs the record holds are tested here, straight-line,
-		// and the loop below just takes the visible ones in walk order; runs beyond the record (3-8 % of the columns) are
-		// scanned when their turn comes.  Same runs, same order per lane as the walk of the counting build (and the oracle).
+		// world bounds do not change inside the element loop.  So the column's first two runs are tested here, straight-line,
+		// and the loop below just takes the visible ones in walk order; further runs (3-8 % of the columns have a third one, which
+		// its record holds as well; a few per thousand more, in the run list) are scanned when their turn comes.  Same runs, same order per lane as the walk of the counting build (and the oracle).
 		bool vis0 = false, vis1 = false;
-		int ovNext = 0; // next run beyond the record to look at: 2, 3, ... (top-down walk) or solidCount - 1, ... 2 (bottom-up walk)
+		int ovNext = 0; // next run beyond the first two to look at: 2, 3, ... (top-down walk) or solidCount - 1, ... 2 (bottom-up walk)
 		// world-space span of a run word {bottomY | (topY - 1) << 16} (cvx_device.h): LOD-0 voxels, integers below 2^17 -- exact as floats, and the
 		// numbers the reference accumulates (see the walk below)
 		auto runSpan = [&](uint32_t w0, float &bottom, float &top) {
@@ -702,7 +702,7 @@ uint2 countInfo = uint2{ 0u, 0u }; // counting build: {RunCount | elementIndex o
 			vis1 = !windowClosed && in1;
 			ovNext = DIR > 0 ? 2 : solidCount - 1;
 		}
-		bool ovPending = !COUNT && !windowClosed && solidCount > 2; // runs beyond the record still to be looked at
+		bool ovPending = !COUNT && !windowClosed && solidCount > 2; // runs beyond the first two still to be looked at
 
 		// Element loop :441-611, realigned for SIMT: every lane first walks its own elements (cheap: decode,
 		// bounds bookkeeping, air / world-bounds culls :445-475) up to its next run that has to be projected;
@@ -715,7 +715,7 @@ uint2 countInfo = uint2{ 0u, 0u }; // counting build: {RunCount | elementIndex o
 			bool found = false;
 			CVX_BEGIN();
 			CVX_WAITPROBE(10);
-			// runs beyond the record: rare, so the scan sits behind one branch (bottom-up they come first, top-down last)
+			// runs beyond the first two: rare, so the scan sits behind one branch (bottom-up they come first, top-down last)
 			auto scanOverflow = [&]() {
 				while (DIR > 0 ? ovNext < solidCount : ovNext >= 2) {
 					// (a record with three runs: run 2 = [worldMin, z.hi + 1], its ColorsIndex = Length of run 0 + Length of run 1; no memory access)
@@ -737,7 +737,7 @@ uint2 countInfo = uint2{ 0u, 0u }; // counting build: {RunCount | elementIndex o
 					scanOverflow();
 				}
 				{ // the next visible run of the record, as selects (no divergent region: a lane without one keeps what it has)
-					const bool free = !found; // (top-down: always -- the scan of the runs beyond the record comes after this)
+					const bool free = !found; // (top-down: always -- the scan of the runs beyond the first two comes after this)
 					const bool take0 = ((int)free & (int)(DIR > 0 ? vis0 : (vis0 && !vis1))) != 0;
 					const bool take1 = ((int)free & (int)(DIR > 0 ? (vis1 && !vis0) : vis1)) != 0;
 					const bool take = ((int)take0 | (int)take1) != 0;
@@ -798,7 +798,7 @@ uint2 countInfo = uint2{ 0u, 0u }; // counting build: {RunCount | elementIndex o
 			if (COUNT ? !found : CVX_RARE(!found)) { // (rendering build: only a lane that has nothing visible left in the record)
 				if (COUNT && solidIndex == solidCount) { consumed = (countInfo.x & 0xFFFFu) + 1u; } // walked on to the end guard
 				if (COUNT) { break; }
-				if (DIR > 0) { // top-down the runs beyond the record come last (here, behind the same rare branch)
+				if (DIR > 0) { // top-down the runs beyond the first two come last (here, behind the same rare branch)
 					scanOverflow();
 				}
 				if (!found) {
@@ -821,7 +821,7 @@ uint2 countInfo = uint2{ 0u, 0u }; // counting build: {RunCount | elementIndex o
 			const bool faceBottom = ((int)!faceTop & (int)(portionBottom > cameraPosYNormalized)) != 0;
 			const bool faceWanted = (((int)faceTop & (int)!(elementBoundsMax > worldBoundsMax)) | ((int)faceBottom & (int)!(elementBoundsMin < worldBoundsMin))) != 0; // (faceBottom implies !faceTop)
 			// (unconditional: both addresses are colours of this run, and a branch around one load costs more than the load)
-			const uint32_t secondaryColor = ld_color(arena, worldColumnColorsOff + (uint32_t)(faceTop ? elementColorsIndex : elementColorsIndex + elementLength - 1) * 4u);
+			const uint32_t secondaryColor = ld_color(arena, worldColumnColorsOff + (uint32_t)(faceTop ? elementColorsIndex : elementColorsIndex + elementLength - 1) * (CVX_COLOR_STRIDE * 4u));
 
 			// side of the run, :484-542
 			CVX_COUNT(4);
@@ -922,7 +922,7 @@ uint2 countInfo = uint2{ 0u, 0u }; // counting build: {RunCount | elementIndex o
 									float wuy = m_lerp(uvAy, uvBy, l);
 									float u = wuy / wux;
 									int colorIdx = m_clampi(f2i_floor(u), 0, elementLength - 1) + elementColorsIndex;
-									return worldColumnColorsOff + (uint32_t)colorIdx * 4u;
+									return worldColumnColorsOff + (uint32_t)colorIdx * (CVX_COLOR_STRIDE * 4u); // (colour k of a column lives one 128-byte line behind its colour k - 1, cvx_device.h)
 								};
 								// Up to four pixels per trip: all their colour loads are in flight before the first store waits for its colour (a load's
 								// latency is what a trip costs, not its arithmetic).  Same pixels, same order of stores per lane.  (Two per trip until

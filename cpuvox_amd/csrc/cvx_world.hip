@@ -146,9 +146,29 @@ int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byt
 	H.records.assign(recordCount, uint4{ 0u, 0u, 0u, 0u });
 	H.counts.assign(recordCount, uint2{ 0u, 0u });
 	H.runs.assign(listEntries + 4, uint2{ 0u, 0u }); // never empty; the kernel may read two entries at any block
-	const size_t kPoolPad = 4; // zeroed guard entries around the colours
-	H.elements.assign((size_t)colourTotal + 2 * kPoolPad, 0u);
-	size_t listCursor = 0, colourCursor = kPoolPad;
+	// Colours: blocks of CVX_COLOR_BLOCK_X x CVX_COLOR_BLOCK_Z columns, colour k of the block's 32 columns in ONE 128-byte line (cvx_device.h).
+	// A block is as deep as its column with the most colours.
+	(void)colourTotal;
+	const int64_t blocksX = (usedX + CVX_COLOR_BLOCK_X - 1) / CVX_COLOR_BLOCK_X, blocksZ = (usedZ + CVX_COLOR_BLOCK_Z - 1) / CVX_COLOR_BLOCK_Z;
+	std::vector<uint32_t> blockBase((size_t)(blocksX * blocksZ), 0u);
+	size_t colourEntries = CVX_COLOR_STRIDE; // (one line of zeros in front: no column's base is 0, cvx_device.h)
+	for (int64_t bx = 0; bx < blocksX; bx++) {
+		for (int64_t bz = 0; bz < blocksZ; bz++) {
+			uint32_t depth = 0;
+			for (int64_t cx = bx * CVX_COLOR_BLOCK_X; cx < std::min<int64_t>(usedX, (bx + 1) * CVX_COLOR_BLOCK_X); cx++) {
+				for (int64_t cz = bz * CVX_COLOR_BLOCK_Z; cz < std::min<int64_t>(usedZ, (bz + 1) * CVX_COLOR_BLOCK_Z); cz++) {
+					depth = std::max(depth, colourCounts[(size_t)(cx * usedZ + cz)]);
+				}
+			}
+			blockBase[(size_t)(bx * blocksZ + bz)] = (uint32_t)colourEntries;
+			colourEntries += (size_t)depth * CVX_COLOR_STRIDE;
+		}
+	}
+	if (colourEntries + CVX_COLOR_STRIDE >= ((size_t)1 << 30)) {
+		return Fail(ctx, CVX_ERR_CAPACITY, "LOD %d: %.2f G colour slots (the records address 2^30)", lod, (double)colourEntries / 1e9);
+	}
+	H.elements.assign(colourEntries + CVX_COLOR_STRIDE, 0u);
+	size_t listCursor = 0;
 	for (int64_t cx = 0; cx < usedX; cx++) {
 		for (int64_t cz = 0; cz < usedZ; cz++) {
 			const int64_t i = cx * usedZ + cz; // World.GetIndexKnownInBounds, World.cs:145-149
@@ -161,10 +181,11 @@ int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byt
 			const size_t at = ((size_t)cx << rowShift) + (size_t)cz;
 			const Shape sh = shapeOf(h);
 			const uint32_t code = codeOf(h, sh);
-			// RLEColumn.ColorPointer (World.cs:185) in the packed pool (>= 4: a listed column's x is never 0, the empty column's always)
-			const uint32_t colorsBase = (uint32_t)colourCursor;
-			std::memcpy(H.elements.data() + colourCursor, elements + off + n + 2, (size_t)colourCounts[(size_t)i] * 4);
-			colourCursor += colourCounts[(size_t)i];
+			// RLEColumn.ColorPointer (World.cs:185) as the slot of the column's first colour (>= 32: a listed column's x is never 0, the empty column's always)
+			const uint32_t colorsBase = blockBase[(size_t)((cx / CVX_COLOR_BLOCK_X) * blocksZ + cz / CVX_COLOR_BLOCK_Z)] + (uint32_t)((cx % CVX_COLOR_BLOCK_X) * CVX_COLOR_BLOCK_Z + cz % CVX_COLOR_BLOCK_Z);
+			for (uint32_t k = 0; k < colourCounts[(size_t)i]; k++) {
+				H.elements[(size_t)colorsBase + (size_t)k * CVX_COLOR_STRIDE] = elements[off + n + 2 + k];
+			}
 			const uint32_t bounds = (uint32_t)h.worldMin | ((uint32_t)h.worldMax << 16);
 			uint32_t z = 0, w = 0;
 			if (code == 0u) {
