@@ -228,3 +228,25 @@ def test_counter_summary_serves_the_drivers_argument_vector(tmp_path, monkeypatc
     # a summary of rounds 1-4 (no per-launch column) still serves exactly the run that collected it, nothing else
     old = os.path.join(ROOT, "profiles", "r04_pmc_render_kernel.csv")
     assert bench.read_counter_summary(old, 2, 10) is not None and bench.read_counter_summary(old, 5, 20) is None
+
+
+def test_gpu_objects_do_not_depend_on_the_build_directory(tmp_path):
+    """bench.py attaches the committed counter summary only to the library whose sha-256 it is stamped with, and the GPU box rebuilds stale targets at
+    its own scratch path: the product library's objects are compiled with a fixed compilation-unit id (csrc/Makefile), so the same sources give the
+    same bytes in any directory.  Checked on the smallest translation unit, built through the Makefile's own rule in two places."""
+    import hashlib
+    import shutil
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("hipcc") is None:
+        pytest.skip("no hipcc here")
+    digests = []
+    for name in ("a", "somewhere/else"):
+        tree = tmp_path / name
+        shutil.copytree(os.path.join(root, "cpuvox_amd", "csrc"), tree / "cpuvox_amd" / "csrc", ignore=shutil.ignore_patterns(".obj", "*.o", "*.so"))
+        shutil.copytree(os.path.join(root, "include"), tree / "include")
+        obj = tree / "cpuvox_amd" / "csrc" / ".obj" / "cvx_shard.o"
+        subprocess.run(["make", "-C", str(tree / "cpuvox_amd" / "csrc"), str(obj)], check=True, capture_output=True, text=True, timeout=600)
+        digests.append(hashlib.sha256(obj.read_bytes()).hexdigest())
+    assert digests[0] == digests[1]
