@@ -1,7 +1,15 @@
 #!/bin/bash
-mkdir -p gpurun_out/r05k
-timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "scene or fuzz or run_rich or foreign or long_world" > gpurun_out/r05k/gputests.log 2>&1; echo "tests rc=$?"; tail -2 gpurun_out/r05k/gputests.log
-timeout -k 10 600 python3 tools/ab_fast.py "libcpuvox_gpu_base.so libcpuvox_gpu.so" --contexts 3 --latency 200 > gpurun_out/r05k/ab.txt 2>&1
-tail -8 gpurun_out/r05k/ab.txt
-timeout -k 10 600 python3 tools/ab_fast.py "libcpuvox_gpu_base.so libcpuvox_gpu.so" --contexts 2 --width 3840 --height 2160 --frames 64 > gpurun_out/r05k/ab4k.txt 2>&1
-tail -3 gpurun_out/r05k/ab4k.txt
+mkdir -p gpurun_out/r05l
+for g in raybuffer image; do
+timeout -k 10 500 python3 bench.py --gpus 2 --backend gloo --gather $g --steps 3 --warmup 1 --frames 64 --cpu-seconds 0 > gpurun_out/r05l/gloo_$g.json 2> gpurun_out/r05l/gloo_$g.err; echo "rc=$?"; python3 -c "
+import json;d=json.load(open('gpurun_out/r05l/gloo_$g.json'));print(d.get('value'),d.get('exchange_verified'),d.get('exchange_path'),d.get('n_gpus'))"
+done
+python3 - <<'PY'
+import time,sys
+sys.path.insert(0,'.')
+from cpuvox_amd import gpu,host
+ws=host.WorldSet.procedural(2048,2048,2048,0x5EED2048)
+ctx=gpu.Context(0)
+t=time.time(); ctx.upload_world(ws); print('upload_world proc2048 (6 levels, host side): %.2f s'%(time.time()-t))
+ctx.close()
+PY
