@@ -582,6 +582,27 @@ def test_foreign_blob_columns_go_through_the_run_list():
         ctx.close()
 
 
+def test_one_level_uploaded_again_keeps_the_others(contexts):
+    """cvx_world_upload of ONE level after a draw: the next draw lays out a new arena, takes the uploaded level from the host and every other
+    level (records, run list, counts, colours) from the old arena, device to device.  Same pictures and counters as before, against the oracle."""
+    name = "proc256_t075_lod8"  # lodError 8: rays reach the higher levels
+    ws, fr, W, H = scenes.scene_frame(name)
+    ctx = contexts(scenes.SCENES[name][0], W, H)
+    o_td, o_lr, cnt = O.draw_segments(ws, fr, W, H, clear=CLEAR)
+    try:
+        for lod in (1, 0, 3):
+            i = ws.info(lod)
+            ctx._check(gpu.lib().cvx_world_upload(ctx._h, lod, i.storage, i.byteLength, i.dimX, i.dimY, i.dimZ, i.columnCount))
+            for counting in (True, False):
+                g_td, g_lr = _render_gpu(ctx, fr, counters=counting)
+                _compare(f"{name} after level {lod} again, counting={counting}", fr, g_td, g_lr, o_td, o_lr)
+                if counting:
+                    gc = ctx.counters()
+                    assert (gc.S, gc.E, gc.C, gc.P, gc.R) == (cnt.S, cnt.E, cnt.C, cnt.P, cnt.R), (gc.as_dict(), cnt.as_dict())
+    finally:
+        ctx.upload_world(ws)
+
+
 def test_long_world_far_edge_checkpoints(contexts):
     """a ray that makes more than ~9 000 crossings on one axis at one LOD level.  The column loop tests the ray's position
     only beyond a stop distance `tMax + (n - 4) tDelta`; the DDA's own additions drift by ~n^2 2^-24 tDelta, so over 16 384 crossings the three
