@@ -1,3 +1,4 @@
 #!/bin/bash
-mkdir -p gpurun_out/r05l
-timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "uploaded_again or device_built" > gpurun_out/r05l/t.log 2>&1; echo rc=$?; tail -5 gpurun_out/r05l/t.log
+mkdir -p gpurun_out/r05n
+sha256sum cpuvox_amd/libcpuvox_gpu.so | cut -c1-16
+timeout -k 10 1150 python3 tools/soak.py 8000 > gpurun_out/r05n/soak_long.txt 2>&1; echo rc=$?; tail -2 gpurun_out/r05n/soak_long.txt
