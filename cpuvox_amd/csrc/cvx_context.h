@@ -50,6 +50,7 @@ struct cvx_context {
 		size_t recordsBytes = 0, runsBytes = 0, countsBytes = 0, elementsBytes = 0;
 		bool pending = false;           // host vectors hold data that is not in the arena yet
 		int rowShift = 0;
+		int colorShift = 7;             // log2 of the bytes between two colours of a column (cvx_device.h)
 	};
 	HostLevel hostLevel[CVX_LOD_LEVELS];
 	uint8_t *arena = nullptr;

@@ -56,12 +56,15 @@ struct DevWorldLevel {
 	uint32_t runsOff;     // run list: uint2 per solid run of the listed columns
 	// The columns' colours (ColorARGB32; the reference's pool interleaves them with the RLE elements, which the kernel never reads), in blocks of 4 x 8
 	// columns: colour k of the block's 32 columns fills ONE 128-byte line, colour k of a column lives CVX_COLOR_STRIDE entries behind its colour k - 1,
-	// and a block is as deep as its column with the most colours.  What the rays of a wave read at a step are the first few colours (the top voxels)
+	// and a block is as deep as its column with the most colours (~2.5 x the colours of a terrain; a level whose blocks would take more than 4 x keeps
+	// its colours column after column: `colorShift`).  What the rays of a wave read at a step are the first few colours (the top voxels)
 	// of neighbouring columns: one line for all of them, where the column-after-column order spent a line on three columns' full stacks.
 	uint32_t elementsOff;
 	int32_t shift;        // lod
 	int32_t rowShift;     // log2 of the records per row (columns of this level along z)
 	uint32_t countsOff;   // uint2 per column, indexed like the records
+	int32_t colorShift;   // log2 of the bytes between two colours of a column: 7 (blocks) or 2 (column after column, for worlds whose blocks would waste > 4 x)
+	int32_t pad_;
 };
 
 struct DevWorld {

@@ -363,6 +363,8 @@ int SyncWorld(cvx_context *ctx)
 			L.shift = i;
 			L.rowShift = H.rowShift;
 			L.countsOff = (uint32_t)countsAt[i];
+			L.colorShift = H.colorShift;
+			L.pad_ = 0;
 		}
 		if (ctx->arena) { (void)hipFree(ctx->arena); }
 		ctx->arena = arena;

@@ -821,7 +821,7 @@ uint2 countInfo = uint2{ 0u, 0u }; // counting build: {RunCount | elementIndex o
 			const bool faceBottom = ((int)!faceTop & (int)(portionBottom > cameraPosYNormalized)) != 0;
 			const bool faceWanted = (((int)faceTop & (int)!(elementBoundsMax > worldBoundsMax)) | ((int)faceBottom & (int)!(elementBoundsMin < worldBoundsMin))) != 0; // (faceBottom implies !faceTop)
 			// (unconditional: both addresses are colours of this run, and a branch around one load costs more than the load)
-			const uint32_t secondaryColor = ld_color(arena, worldColumnColorsOff + (uint32_t)(faceTop ? elementColorsIndex : elementColorsIndex + elementLength - 1) * (CVX_COLOR_STRIDE * 4u));
+			const uint32_t secondaryColor = ld_color(arena, worldColumnColorsOff +((uint32_t)(faceTop ? elementColorsIndex : elementColorsIndex + elementLength - 1) << L.colorShift));
 
 			// side of the run, :484-542
 			CVX_COUNT(4);
@@ -922,7 +922,7 @@ uint2 countInfo = uint2{ 0u, 0u }; // counting build: {RunCount | elementIndex o
 									float wuy = m_lerp(uvAy, uvBy, l);
 									float u = wuy / wux;
 									int colorIdx = m_clampi(f2i_floor(u), 0, elementLength - 1) + elementColorsIndex;
-									return worldColumnColorsOff + (uint32_t)colorIdx * (CVX_COLOR_STRIDE * 4u); // (colour k of a column lives one 128-byte line behind its colour k - 1, cvx_device.h)
+									return worldColumnColorsOff + ((uint32_t)colorIdx << L.colorShift); // (colour k of a column lives one 128-byte line behind its colour k - 1, cvx_device.h)
 								};
 								// Up to four pixels per trip: all their colour loads are in flight before the first store waits for its colour (a load's
 								// latency is what a trip costs, not its arithmetic).  Same pixels, same order of stores per lane.  (Two per trip until

@@ -147,8 +147,8 @@ int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byt
 	H.counts.assign(recordCount, uint2{ 0u, 0u });
 	H.runs.assign(listEntries + 4, uint2{ 0u, 0u }); // never empty; the kernel may read two entries at any block
 	// Colours: blocks of CVX_COLOR_BLOCK_X x CVX_COLOR_BLOCK_Z columns, colour k of the block's 32 columns in ONE 128-byte line (cvx_device.h).
-	// A block is as deep as its column with the most colours.
-	(void)colourTotal;
+	// A block is as deep as its column with the most colours: ~2.5 x the colours themselves for a terrain.  A world of a few deep columns among
+	// empty ones would pay up to 32 x: beyond 4 x the level keeps its colours column after column instead (stride 1).
 	const int64_t blocksX = (usedX + CVX_COLOR_BLOCK_X - 1) / CVX_COLOR_BLOCK_X, blocksZ = (usedZ + CVX_COLOR_BLOCK_Z - 1) / CVX_COLOR_BLOCK_Z;
 	std::vector<uint32_t> blockBase((size_t)(blocksX * blocksZ), 0u);
 	size_t colourEntries = CVX_COLOR_STRIDE; // (one line of zeros in front: no column's base is 0, cvx_device.h)
@@ -164,10 +164,15 @@ int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byt
 			colourEntries += (size_t)depth * CVX_COLOR_STRIDE;
 		}
 	}
+	const bool blocked = colourEntries <= 4 * (size_t)colourTotal + 65536 && colourEntries <= ((size_t)1 << 29); // (... and at most half of what the 32-bit offsets address)
+	const size_t colourStride = blocked ? CVX_COLOR_STRIDE : 1;
+	if (!blocked) { colourEntries = CVX_COLOR_STRIDE + (size_t)colourTotal; }
 	if (colourEntries + CVX_COLOR_STRIDE >= ((size_t)1 << 30)) {
 		return Fail(ctx, CVX_ERR_CAPACITY, "LOD %d: %.2f G colour slots (the records address 2^30)", lod, (double)colourEntries / 1e9);
 	}
 	H.elements.assign(colourEntries + CVX_COLOR_STRIDE, 0u);
+	H.colorShift = blocked ? 7 : 2; // log2 of the bytes between two colours of a column
+	size_t denseCursor = CVX_COLOR_STRIDE;
 	size_t listCursor = 0;
 	for (int64_t cx = 0; cx < usedX; cx++) {
 		for (int64_t cz = 0; cz < usedZ; cz++) {
@@ -182,10 +187,12 @@ int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byt
 			const Shape sh = shapeOf(h);
 			const uint32_t code = codeOf(h, sh);
 			// RLEColumn.ColorPointer (World.cs:185) as the slot of the column's first colour (>= 32: a listed column's x is never 0, the empty column's always)
-			const uint32_t colorsBase = blockBase[(size_t)((cx / CVX_COLOR_BLOCK_X) * blocksZ + cz / CVX_COLOR_BLOCK_Z)] + (uint32_t)((cx % CVX_COLOR_BLOCK_X) * CVX_COLOR_BLOCK_Z + cz % CVX_COLOR_BLOCK_Z);
+			const uint32_t colorsBase = blocked ? blockBase[(size_t)((cx / CVX_COLOR_BLOCK_X) * blocksZ + cz / CVX_COLOR_BLOCK_Z)] + (uint32_t)((cx % CVX_COLOR_BLOCK_X) * CVX_COLOR_BLOCK_Z + cz % CVX_COLOR_BLOCK_Z)
+			                                    : (uint32_t)denseCursor;
 			for (uint32_t k = 0; k < colourCounts[(size_t)i]; k++) {
-				H.elements[(size_t)colorsBase + (size_t)k * CVX_COLOR_STRIDE] = elements[off + n + 2 + k];
+				H.elements[(size_t)colorsBase + (size_t)k * colourStride] = elements[off + n + 2 + k];
 			}
+			denseCursor += colourCounts[(size_t)i];
 			const uint32_t bounds = (uint32_t)h.worldMin | ((uint32_t)h.worldMax << 16);
 			uint32_t z = 0, w = 0;
 			if (code == 0u) {

@@ -582,6 +582,32 @@ def test_foreign_blob_columns_go_through_the_run_list():
         ctx.close()
 
 
+def test_sparse_deep_world_keeps_its_colours_column_after_column():
+    """The device keeps a level's colours in blocks of 4 x 8 columns, each as deep as its deepest column (cvx_device.h) -- unless that would take more
+    than four times the colours themselves: a hundred deep columns in an empty world, as here, keep theirs column after column (`colorShift` 2
+    instead of 7).  Same pictures and counters as the oracle either way."""
+    dims = (64, 256, 64)
+    x, y, z, argb = _random_alpha_world(dims, 31, 100, 4)
+    ws = host.WorldSet.from_voxels(dims, x, y, z, argb, threads=4)
+    W, H = 320, 200
+    ctx = gpu.Context(0)
+    try:
+        ctx.upload_world(ws)
+        ctx.set_resolution(W, H)
+        for pos, eul in (((32.3, 130.0, -20.2), (5.0, 0.0, 0.0)), ((32.3, 300.0, 32.2), (80.0, 30.0, 0.0)), ((-10.3, 100.0, 70.2), (-10.0, 120.0, 0.0)), ((32.3, 128.0, 32.2), (0.0, 45.0, 0.0))):
+            fr = scenes.make_frame(ws, W, H, pos, eul)
+            o_td, o_lr, cnt = O.draw_segments(ws, fr, W, H, clear=CLEAR)
+            assert cnt.P > 0
+            for counting in (True, False):
+                g_td, g_lr = _render_gpu(ctx, fr, counters=counting)
+                _compare(f"sparse world pos={pos} eul={eul} counting={counting}", fr, g_td, g_lr, o_td, o_lr)
+                if counting:
+                    gc = ctx.counters()
+                    assert (gc.S, gc.E, gc.C, gc.P, gc.R) == (cnt.S, cnt.E, cnt.C, cnt.P, cnt.R), (gc.as_dict(), cnt.as_dict())
+    finally:
+        ctx.close()
+
+
 def test_one_level_uploaded_again_keeps_the_others(contexts):
     """cvx_world_upload of ONE level after a draw: the next draw lays out a new arena, takes the uploaded level from the host and every other
     level (records, run list, counts, colours) from the old arena, device to device.  Same pictures and counters as before, against the oracle."""
