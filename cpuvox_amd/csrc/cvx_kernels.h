@@ -711,7 +711,7 @@ uint2 countInfo = uint2{ 0u, 0u }; // counting build: {RunCount | elementIndex o
 		// elements each lane consumes is unchanged.
 		// (rendering build: a lane stays in the loop exactly as long as it has a visible run left -- no trailing "nothing found" pass)
 		while (COUNT || vis0 || vis1 || CVX_RARE(ovPending)) {
-			int elementColorsIndex = 0, elementLength = 0;
+			int elementColorsIndex, elementLength; // (no initial values: read only once `found`, which every path that sets it writes them before)
 			bool found = false;
 			CVX_BEGIN();
 			CVX_WAITPROBE(10);
@@ -933,11 +933,11 @@ uint2 countInfo = uint2{ 0u, 0u }; // counting build: {RunCount | elementIndex o
 									todo &= todo - 1u;
 									const uint32_t c0 = ld_color(arena, colourOffset(y0));
 									const bool second = todo != 0u;
-									int y1 = y0;
-									uint32_t c1 = 0u;
+									// (no initial values: each of these is written and read under the same condition, and an initialiser is seven moves per trip
+									// for the lanes that never look at it)
+									int y1, y2, y3;
+									uint32_t c1, c2, c3;
 									bool third = false, fourth = false;
-									int y2 = y0, y3 = y0;
-									uint32_t c2 = 0u, c3 = 0u;
 									if (second) {
 										y1 = (w << 5) + (__ffs((int)todo) - 1);
 										todo &= todo - 1u;
@@ -963,7 +963,7 @@ uint2 countInfo = uint2{ 0u, 0u }; // counting build: {RunCount | elementIndex o
 											if (fourth) { st_pixel_loop(tileOut, laneByteOff, y3, c3); }
 										}
 									}
-									if (COUNT) { const unsigned int n_ = 1u + (second ? 1u : 0u) + (third ? 1u : 0u) + (fourth ? 1u : 0u); cnt.C += n_; cnt.P += n_; }
+									if (COUNT) { const unsigned int n_ = 1u + (second ? 1u : 0u) + (second && third ? 1u : 0u) + (second && third && fourth ? 1u : 0u); cnt.C += n_; cnt.P += n_; }
 								} while (todo != 0u);
 							}
 						}
