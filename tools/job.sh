@@ -1,7 +1,8 @@
 #!/bin/bash
-mkdir -p gpurun_out/r05q
-timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "scene or fuzz or run_rich or foreign or sparse" > gpurun_out/r05q/t.log 2>&1; echo "tests rc=$?"; tail -2 gpurun_out/r05q/t.log
-timeout -k 10 600 python3 tools/ab_fast.py "libcpuvox_gpu_base.so libcpuvox_gpu_ni1.so libcpuvox_gpu.so" --contexts 3 --latency 200 > gpurun_out/r05q/ab.txt 2>&1
-tail -9 gpurun_out/r05q/ab.txt
-timeout -k 10 600 python3 tools/ab_fast.py "libcpuvox_gpu_base.so libcpuvox_gpu.so" --contexts 2 --width 3840 --height 2160 --frames 64 > gpurun_out/r05q/ab4k.txt 2>&1
-tail -3 gpurun_out/r05q/ab4k.txt
+mkdir -p gpurun_out/r05r
+sha256sum cpuvox_amd/libcpuvox_gpu.so | cut -c1-16
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/r05r/gputests.log 2>&1; echo "tests rc=$?"; tail -2 gpurun_out/r05r/gputests.log
+timeout -k 10 1000 python3 tools/soak.py 2500 > gpurun_out/r05r/soak.txt 2>&1; tail -1 gpurun_out/r05r/soak.txt
+timeout -k 10 600 python3 tools/soak.py bench > gpurun_out/r05r/soak_bench.txt 2>&1; tail -1 gpurun_out/r05r/soak_bench.txt
+bash tools/profile_round.sh r05 > gpurun_out/r05r/profile.log 2>&1; tail -1 gpurun_out/r05r/profile.log | cut -c1-100
+sha256sum cpuvox_amd/libcpuvox_gpu.so | cut -c1-16
