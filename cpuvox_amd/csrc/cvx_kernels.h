@@ -908,6 +908,10 @@ uint2 countInfo = uint2{ 0u, 0u }; // counting build: {RunCount | elementIndex o
 						CVX_COUNT(10);
 						reduce_pixel_horizon(seen, sshift, omin, omax, rbMin, rbMax, nextFreePixelMin, nextFreePixelMax, frustumBoundsMin, frustumBoundsMax);
 						CVX_END(4);
+						// per-run constants of the cheap texture row below
+						const float texRd = __builtin_amdgcn_rcpf(boundsY - boundsX);
+						const float texA1 = uvBx - uvAx, texA2 = uvBy - uvAy;
+						const float texA1s = 40.0f * 0x1p-24f * fabsf(texA1), texA2s = 40.0f * 0x1p-24f * fabsf(texA2), texBxs = 40.0f * 0x1p-24f * fabsf(uvAx), texBys = 40.0f * 0x1p-24f * fabsf(uvAy);
 						for (int w = rbMin >> 5; w <= (rbMax >> 5); w++) { // pixel loop :519-533 over unseen bits
 							const uint32_t range = range_mask(w, rbMin, rbMax);
 							const uint32_t m = seen[w << sshift];
@@ -916,12 +920,41 @@ uint2 countInfo = uint2{ 0u, 0u }; // counting build: {RunCount | elementIndex o
 								seen[w << sshift] = m | range;
 								frustumDirMaxWorld = CVX_FLOAT_EPSILON;
 								// perspective-correct colour of pixel y of the run's side, :524-531
-								auto colourOffset = [&](int y) -> uint32_t {
+								// the reference's texture row of pixel y: floor of u = lerp(uvA.y, uvB.y, l) / lerp(uvA.x, uvB.x, l), l = unlerp(bounds, y) -- two IEEE divisions
+								auto exactRow = [&](int y) -> int {
 									float l = ((float)y - boundsX) / (boundsY - boundsX); // unlerp
 									float wux = m_lerp(uvAx, uvBx, l);
 									float wuy = m_lerp(uvAy, uvBy, l);
 									float u = wuy / wux;
-									int colorIdx = m_clampi(f2i_floor(u), 0, elementLength - 1) + elementColorsIndex;
+									return f2i_floor(u);
+								};
+								// Round 5: only floor(u) is ever used, so u is first computed the cheap way (hardware reciprocals, fused multiply-adds: u') together with a
+								// bound D on |u - u'| that covers every rounding of both computations; where u' lies farther than D from the nearest integer, u and u' have
+								// the same floor.  The other pixels (a few per ten thousand) take the reference's divisions.  Derivation (e = 2^-24; all of l, wux, wuy as
+								// the reference rounds them against the primed ones here; n = y - boundsX and d = boundsY - boundsX are the same floats in both):
+								//   l = fl(n / d), l' = fl(n * rcp(d)), rcp within one ulp                          =>  |l - l'| <= 2^-22 |n / d|
+								//   wux = fl(uvA.x + fl(l * a1)), wux' = fma(l', a1, uvA.x), a1 = fl(uvB.x - uvA.x)   =>  |wux - wux'| <= 9 e (|uvA.x| + |l'| |a1|) =: Ex;  Ey likewise
+								//   if Ex <= |wux'| / 2:  |wuy / wux - wuy' / wux'| <= 2 (Ey + |wuy' / wux'| Ex) / |wux'|;  the final division / rcp + multiply: 4.2 e |u'| more.
+								//   D = (Sy + (|u'| + 1) Sx) |rcp(wux')| + 8 e |u'|  with Sx = 40 e (|uvA.x| + |l'| |a1|) >= 2.2 x (2 Ex), Sy likewise: the "+ 1" makes D >= 1
+								//   (no pixel is certain) whenever Ex > |wux'| / 2; |u'| >= 2^21 gives D > 1/2 too, so a certain u' is far inside the int range; a NaN or an
+								//   infinity anywhere makes the comparison false.
+								auto textureRow = [&](int y) -> int {
+									if (COUNT) { return exactRow(y); }
+									const float n = (float)y - boundsX;
+									const float lq = n * texRd;
+									const float wx = __builtin_fmaf(lq, texA1, uvAx), wy = __builtin_fmaf(lq, texA2, uvAy);
+									const float r = __builtin_amdgcn_rcpf(wx);
+									const float uq = wy * r;
+									const float sx = __builtin_fmaf(fabsf(lq), texA1s, texBxs), sy = __builtin_fmaf(fabsf(lq), texA2s, texBys);
+									const float bound = __builtin_fmaf(__builtin_fmaf(fabsf(uq), sx, sy + sx), fabsf(r), 0x1p-21f * fabsf(uq));
+									const bool certain = fabsf(uq - rintf(uq)) > bound;
+									int row;
+									asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(row) : "v"(uq));
+									if (CVX_RARE(!certain)) { row = exactRow(y); }
+									return row;
+								};
+								auto colourOffset = [&](int y) -> uint32_t {
+									int colorIdx = m_clampi(textureRow(y), 0, elementLength - 1) + elementColorsIndex;
 									return worldColumnColorsOff + ((uint32_t)colorIdx << L.colorShift); // (colour k of a column lives one 128-byte line behind its colour k - 1, cvx_device.h)
 								};
 								// Up to four pixels per trip: all their colour loads are in flight before the first store waits for its colour (a load's

@@ -1,8 +1,4 @@
 #!/bin/bash
-mkdir -p gpurun_out/r05r
-sha256sum cpuvox_amd/libcpuvox_gpu.so | cut -c1-16
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/r05r/gputests.log 2>&1; echo "tests rc=$?"; tail -2 gpurun_out/r05r/gputests.log
-timeout -k 10 1000 python3 tools/soak.py 2500 > gpurun_out/r05r/soak.txt 2>&1; tail -1 gpurun_out/r05r/soak.txt
-timeout -k 10 600 python3 tools/soak.py bench > gpurun_out/r05r/soak_bench.txt 2>&1; tail -1 gpurun_out/r05r/soak_bench.txt
-bash tools/profile_round.sh r05 > gpurun_out/r05r/profile.log 2>&1; tail -1 gpurun_out/r05r/profile.log | cut -c1-100
-sha256sum cpuvox_amd/libcpuvox_gpu.so | cut -c1-16
+mkdir -p gpurun_out/r05s
+timeout -k 10 600 python3 tools/section_counts.py 128 > gpurun_out/r05s/counts.txt 2>&1
+head -12 gpurun_out/r05s/counts.txt
