@@ -332,6 +332,61 @@ __device__ __forceinline__ bool clip_world_bounds(f3 pMin, f3 pMax, float fMin, 
 	return CVX_OR(CVX_AND(a1, a2), CVX_AND(CVX_AND(n1, n2), CVX_AND(b1, b2)));
 }
 
+// ---- texture row of a side pixel (DrawSegmentRayJob.cs:524-531) -------------------------------------------------------
+// The reference: l = unlerp(bounds, y), u = lerp(uvA.y, uvB.y, l) / lerp(uvA.x, uvB.x, l), row = (int)floor(u) -- two IEEE divisions per pixel.
+__device__ __forceinline__ int tex_row_exact(int y, float boundsX, float boundsY, float uvAx, float uvBx, float uvAy, float uvBy)
+{
+	float l = ((float)y - boundsX) / (boundsY - boundsX); // unlerp
+	float wux = m_lerp(uvAx, uvBx, l);
+	float wuy = m_lerp(uvAy, uvBy, l);
+	float u = wuy / wux;
+	return f2i_floor(u);
+}
+// Round 5: only floor(u) is ever used, so u is first computed the cheap way (hardware reciprocals, fused multiply-adds: u') together with a bound D on
+// |u - u'| that covers every rounding of both computations; where u' lies farther than D from the nearest integer, u and u' have the same floor
+// (`certain`).  The other pixels (a few per thousand) take the reference's divisions.  Derivation (e = 2^-24; l, wux, wuy as the reference rounds them
+// against the primed ones here; n = y - boundsX and d = boundsY - boundsX are the same floats in both):
+//   l = fl(n / d), l' = fl(n * rcp(d)), rcp within one ulp                              =>  |l - l'| <= 2^-22 |n / d|
+//   wux = fl(uvA.x + fl(l * a1)), wux' = fma(l', a1, uvA.x), a1 = fl(uvB.x - uvA.x)       =>  |wux - wux'| <= 9 e (|uvA.x| + |l'| |a1|) =: Ex;  Ey likewise
+//   if Ex <= |wux'| / 2:  |wuy / wux - wuy' / wux'| <= 2 (Ey + |wuy' / wux'| Ex) / |wux'|;  the final division against rcp + multiply: 4.2 e |u'| more
+//   D = (Sy + (|u'| + 1) Sx) |rcp(wux')| + 8 e |u'|  with Sx = 40 e (|uvA.x| + |l'| |a1|) >= 2.2 x (2 Ex), Sy likewise.  The "+ 1" makes D >= 1 (no
+//   pixel is certain) whenever Ex > |wux'| / 2; |u'| >= 2^21 gives D > 1/2 too, so a certain u' is far inside the int range (where the x86 rule of
+//   f2i_floor is the plain floor); a NaN or an infinity anywhere makes the comparison false.  Outside the normal range: |d| > 2^100 makes every pixel of the
+//   run uncertain, 2^-110 |wux'| in D does the same for |wux'| > 2^126 (denormal reciprocals), and Sx >= 2^-140 covers what underflowing products lose.
+//   cvx_selftest_math op 16 compares the two forms on the device (tests: 2^24 samples incl. float soup, no certain row may differ).
+struct TexRun { // per run: what the cheap row needs of (boundsX, boundsY, uvA, uvB)
+	float rd, a1, a2, a1s, a2s, bxs, bys;
+};
+__device__ __forceinline__ TexRun tex_run(float boundsX, float boundsY, float uvAx, float uvBx, float uvAy, float uvBy)
+{
+	TexRun T;
+	const float d = boundsY - boundsX;
+	T.rd = fabsf(d) <= 0x1p100f ? __builtin_amdgcn_rcpf(d) : __builtin_nanf(""); // (a reciprocal below 2^-126 is not "within one ulp": no pixel of such a run is certain)
+	T.a1 = uvBx - uvAx;
+	T.a2 = uvBy - uvAy;
+	const float k = 40.0f * 0x1p-24f;
+	T.a1s = k * fabsf(T.a1);
+	T.a2s = k * fabsf(T.a2);
+	T.bxs = __builtin_fmaf(k, fabsf(uvAx), 0x1p-140f); // (the floor covers what an underflowing product can lose: 2^-149 per operation)
+	T.bys = k * fabsf(uvAy);
+	return T;
+}
+__device__ __forceinline__ int tex_row_cheap(int y, float boundsX, float uvAx, float uvAy, const TexRun &T, bool &certain)
+{
+	const float n = (float)y - boundsX;
+	const float lq = n * T.rd;
+	const float wx = __builtin_fmaf(lq, T.a1, uvAx), wy = __builtin_fmaf(lq, T.a2, uvAy);
+	const float r = __builtin_amdgcn_rcpf(wx);
+	const float uq = wy * r;
+	const float sx = __builtin_fmaf(fabsf(lq), T.a1s, T.bxs), sy = __builtin_fmaf(fabsf(lq), T.a2s, T.bys);
+	// (the |wux'| term: beyond 2^126 its reciprocal is denormal, not "within one ulp" -- the bound then exceeds every distance)
+	const float bound = __builtin_fmaf(__builtin_fmaf(fabsf(uq), sx, sy + sx), fabsf(r), __builtin_fmaf(fabsf(wx), 0x1p-110f, 0x1p-21f * fabsf(uq)));
+	certain = fabsf(uq - rintf(uq)) > bound;
+	int row;
+	asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(row) : "v"(uq));
+	return row;
+}
+
 // ---- seen-pixel bitmask in LDS ---------------------------------------------
 // Word w of a lane lives at seen[w << sshift]: the words of the wave's lanes are interleaved with a stride of 64, or of
 // the lane count of a sub-tile (a tile whose window needs many words is rendered by narrower waves, so that every
@@ -908,10 +963,6 @@ uint2 countInfo = uint2{ 0u, 0u }; // counting build: {RunCount | elementIndex o
 						CVX_COUNT(10);
 						reduce_pixel_horizon(seen, sshift, omin, omax, rbMin, rbMax, nextFreePixelMin, nextFreePixelMax, frustumBoundsMin, frustumBoundsMax);
 						CVX_END(4);
-						// per-run constants of the cheap texture row below
-						const float texRd = __builtin_amdgcn_rcpf(boundsY - boundsX);
-						const float texA1 = uvBx - uvAx, texA2 = uvBy - uvAy;
-						const float texA1s = 40.0f * 0x1p-24f * fabsf(texA1), texA2s = 40.0f * 0x1p-24f * fabsf(texA2), texBxs = 40.0f * 0x1p-24f * fabsf(uvAx), texBys = 40.0f * 0x1p-24f * fabsf(uvAy);
 						for (int w = rbMin >> 5; w <= (rbMax >> 5); w++) { // pixel loop :519-533 over unseen bits
 							const uint32_t range = range_mask(w, rbMin, rbMax);
 							const uint32_t m = seen[w << sshift];
@@ -920,37 +971,13 @@ uint2 countInfo = uint2{ 0u, 0u }; // counting build: {RunCount | elementIndex o
 								seen[w << sshift] = m | range;
 								frustumDirMaxWorld = CVX_FLOAT_EPSILON;
 								// perspective-correct colour of pixel y of the run's side, :524-531
-								// the reference's texture row of pixel y: floor of u = lerp(uvA.y, uvB.y, l) / lerp(uvA.x, uvB.x, l), l = unlerp(bounds, y) -- two IEEE divisions
-								auto exactRow = [&](int y) -> int {
-									float l = ((float)y - boundsX) / (boundsY - boundsX); // unlerp
-									float wux = m_lerp(uvAx, uvBx, l);
-									float wuy = m_lerp(uvAy, uvBy, l);
-									float u = wuy / wux;
-									return f2i_floor(u);
-								};
-								// Round 5: only floor(u) is ever used, so u is first computed the cheap way (hardware reciprocals, fused multiply-adds: u') together with a
-								// bound D on |u - u'| that covers every rounding of both computations; where u' lies farther than D from the nearest integer, u and u' have
-								// the same floor.  The other pixels (a few per ten thousand) take the reference's divisions.  Derivation (e = 2^-24; all of l, wux, wuy as
-								// the reference rounds them against the primed ones here; n = y - boundsX and d = boundsY - boundsX are the same floats in both):
-								//   l = fl(n / d), l' = fl(n * rcp(d)), rcp within one ulp                          =>  |l - l'| <= 2^-22 |n / d|
-								//   wux = fl(uvA.x + fl(l * a1)), wux' = fma(l', a1, uvA.x), a1 = fl(uvB.x - uvA.x)   =>  |wux - wux'| <= 9 e (|uvA.x| + |l'| |a1|) =: Ex;  Ey likewise
-								//   if Ex <= |wux'| / 2:  |wuy / wux - wuy' / wux'| <= 2 (Ey + |wuy' / wux'| Ex) / |wux'|;  the final division / rcp + multiply: 4.2 e |u'| more.
-								//   D = (Sy + (|u'| + 1) Sx) |rcp(wux')| + 8 e |u'|  with Sx = 40 e (|uvA.x| + |l'| |a1|) >= 2.2 x (2 Ex), Sy likewise: the "+ 1" makes D >= 1
-								//   (no pixel is certain) whenever Ex > |wux'| / 2; |u'| >= 2^21 gives D > 1/2 too, so a certain u' is far inside the int range; a NaN or an
-								//   infinity anywhere makes the comparison false.
+								// the texture row of pixel y: the cheap form where it is certain, the reference's two divisions where not (tex_row_cheap above)
+								const TexRun texRun = COUNT ? TexRun{} : tex_run(boundsX, boundsY, uvAx, uvBx, uvAy, uvBy);
 								auto textureRow = [&](int y) -> int {
-									if (COUNT) { return exactRow(y); }
-									const float n = (float)y - boundsX;
-									const float lq = n * texRd;
-									const float wx = __builtin_fmaf(lq, texA1, uvAx), wy = __builtin_fmaf(lq, texA2, uvAy);
-									const float r = __builtin_amdgcn_rcpf(wx);
-									const float uq = wy * r;
-									const float sx = __builtin_fmaf(fabsf(lq), texA1s, texBxs), sy = __builtin_fmaf(fabsf(lq), texA2s, texBys);
-									const float bound = __builtin_fmaf(__builtin_fmaf(fabsf(uq), sx, sy + sx), fabsf(r), 0x1p-21f * fabsf(uq));
-									const bool certain = fabsf(uq - rintf(uq)) > bound;
-									int row;
-									asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(row) : "v"(uq));
-									if (CVX_RARE(!certain)) { row = exactRow(y); }
+									if (COUNT) { return tex_row_exact(y, boundsX, boundsY, uvAx, uvBx, uvAy, uvBy); }
+									bool certain;
+									int row = tex_row_cheap(y, boundsX, uvAx, uvAy, texRun, certain);
+									if (CVX_RARE(!certain)) { row = tex_row_exact(y, boundsX, boundsY, uvAx, uvBx, uvAy, uvBy); }
 									return row;
 								};
 								auto colourOffset = [&](int y) -> uint32_t {
@@ -1704,6 +1731,19 @@ __global__ void selftest_math_kernel(int op, int n, const float *__restrict__ a,
 {
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) {
+		return;
+	}
+	if (op == 16) { // texture row: groups of four floats {y, boundsX, boundsY, uvA.x} / {uvB.x, uvA.y, uvB.y, -} -> {exact row, cheap row, certain, 0} (int bits)
+		if ((i & 3) == 0 && i + 3 < n) {
+			const int py = (int)a[i];
+			bool certain;
+			const TexRun T = tex_run(a[i + 1], a[i + 2], a[i + 3], b[i], b[i + 1], b[i + 2]);
+			const int cheap = tex_row_cheap(py, a[i + 1], a[i + 3], b[i + 1], T, certain);
+			out[i] = __int_as_float(tex_row_exact(py, a[i + 1], a[i + 2], a[i + 3], b[i], b[i + 1], b[i + 2]));
+			out[i + 1] = __int_as_float(cheap);
+			out[i + 2] = __int_as_float(certain ? 1 : 0);
+			out[i + 3] = 0.0f;
+		}
 		return;
 	}
 	const float x = a[i], y = b[i];

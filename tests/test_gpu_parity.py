@@ -496,6 +496,49 @@ def test_short_division_is_ieee_division(diag_context):
         assert np.array_equal(ctx.selftest_math(15, a, b) == 1.0, (mag >= np.float32(2.0 ** -30)) & (mag <= np.float32(2.0 ** 30)))
 
 
+def test_cheap_texture_row_is_certified(diag_context):
+    """Round 5: the side pixels take their texture row from a cheap computation (hardware reciprocals, fused multiply-adds) wherever a bound on its
+    distance from the reference's value proves the floor equal (`tex_row_cheap`, cvx_kernels.h); the others take the reference's two IEEE divisions.
+    The proof is on paper; this is the experiment: 2^26 samples on the device -- renderer-shaped ones (screen bounds, 1 / z and u / z of two ends, both
+    orders, thin and tall runs, ends close to the near plane), their extremes, and float soup with every special value -- and NOT ONE certain row may
+    differ from the exact one.  Renderer-shaped samples must be certain almost always (the shortcut is worth its instructions)."""
+    ctx = diag_context
+    rng = np.random.default_rng(516)
+    groups = 1 << 20
+    for chunk in range(16):
+        if chunk < 10:
+            span = np.exp(rng.uniform(np.log(1e-4 if chunk >= 6 else 1e-2), np.log(3000.0), groups))
+            bx = rng.uniform(-200.0, 2300.0, groups)
+            by = bx + span
+            y = np.rint(rng.uniform(bx - 1.0, by + 1.0)).clip(-2, 16385)
+            zb = np.exp(rng.uniform(np.log(0.06 if chunk >= 6 else 0.5), np.log(6000.0), groups))
+            zt = zb * np.exp(rng.uniform(-1.5, 1.5, groups)) if chunk % 2 else np.exp(rng.uniform(np.log(0.06), np.log(6000.0), groups))
+            ua = np.rint(np.exp(rng.uniform(0.0, np.log(3000.0), groups)))
+            uvax, uvay, uvbx, uvby = 1.0 / zb, ua / zb, 1.0 / zt, np.zeros(groups)
+            if chunk % 3 == 0:  # the swapped order (:496-499)
+                uvax, uvbx, uvay, uvby = uvbx, uvax, uvby, uvay
+            cols = [y, bx, by, uvax, uvbx, uvay, uvby, np.zeros(groups)]
+            cols = [np.asarray(c, dtype=np.float32) for c in cols]
+        else:
+            cols = [_float_soup(rng, groups) for _ in range(8)]
+            cols[0] = np.rint(rng.uniform(-2, 16385, groups)).astype(np.float32)
+            if chunk >= 13:  # soup in the bounds only / in the texture coordinates only
+                keep = slice(1, 3) if chunk == 13 else slice(3, 7)
+                real = [np.asarray(c, dtype=np.float32) for c in (rng.uniform(0, 1080, groups), rng.uniform(0, 1080, groups) + 1081, 1.0 / rng.uniform(1, 900, groups),
+                                                                  1.0 / rng.uniform(1, 900, groups), rng.uniform(1, 60, groups) / rng.uniform(1, 900, groups), np.zeros(groups))]
+                for k in range(1, 7):
+                    if not (keep.start <= k < keep.stop):
+                        cols[k] = real[k - 1]
+        a = np.stack(cols[:4], axis=1).reshape(-1)
+        b = np.stack(cols[4:], axis=1).reshape(-1)
+        out = ctx.selftest_math(16, a, b).view(np.int32).reshape(-1, 4)
+        exact, cheap, certain = out[:, 0], out[:, 1], out[:, 2] == 1
+        wrong = certain & (exact != cheap)
+        assert not wrong.any(), f"chunk {chunk}: {wrong.sum()} certain rows differ, e.g. inputs {[c[np.flatnonzero(wrong)[0]] for c in cols]} exact {exact[wrong][0]} cheap {cheap[wrong][0]}"
+        if chunk < 6:
+            assert certain.mean() > 0.97, f"chunk {chunk}: only {certain.mean():.4f} of the renderer-shaped rows are certain"
+
+
 def test_run_rich_world_slow_paths(contexts):
     """the paths the ordinary scenes rarely take, forced.  World `stripes128x256x128`: every column a stack of 8 .. 30 solid
     bands (~30 RLE elements per column against ~3 in the terrain worlds), so nearly every drawn column has runs beyond the two a device record
