@@ -1,8 +1,7 @@
 #!/bin/bash
-mkdir -p gpurun_out/r05v
-sha256sum cpuvox_amd/libcpuvox_gpu.so | cut -c1-16
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/r05v/gputests.log 2>&1; echo "tests rc=$?"; tail -2 gpurun_out/r05v/gputests.log
-timeout -k 10 1000 python3 tools/soak.py 2500 > gpurun_out/r05v/soak.txt 2>&1; tail -1 gpurun_out/r05v/soak.txt
-timeout -k 10 600 python3 tools/soak.py bench > gpurun_out/r05v/soak_bench.txt 2>&1; tail -1 gpurun_out/r05v/soak_bench.txt
-bash tools/profile_round.sh r05 > gpurun_out/r05v/profile.log 2>&1; tail -1 gpurun_out/r05v/profile.log | cut -c1-100
-sha256sum cpuvox_amd/libcpuvox_gpu.so | cut -c1-16
+mkdir -p gpurun_out/r05w
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "scene or fuzz or run_rich or foreign or sparse or long_world" > gpurun_out/r05w/t.log 2>&1; echo "tests rc=$?"; tail -2 gpurun_out/r05w/t.log
+timeout -k 10 600 python3 tools/ab_fast.py "libcpuvox_gpu_base.so libcpuvox_gpu.so" --contexts 3 --latency 200 > gpurun_out/r05w/ab.txt 2>&1
+tail -7 gpurun_out/r05w/ab.txt
+timeout -k 10 600 python3 tools/ab_fast.py "libcpuvox_gpu_base.so libcpuvox_gpu.so" --contexts 2 --width 3840 --height 2160 --frames 64 > gpurun_out/r05w/ab4k.txt 2>&1
+tail -3 gpurun_out/r05w/ab4k.txt
