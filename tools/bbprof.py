@@ -30,7 +30,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "cpuvox_amd", "csrc")
 LLVM = "/opt/rocm/lib/llvm/bin"
 KERNEL = "_ZN4cvxk13render_kernelILb0EEEvPK8DevFramePK7DevTilePK8DevWorldP11DevCounters"
-HIPFLAGS = ["-std=c++17", "-Os", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-enable-post-misched=0", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
+HIPFLAGS = ["-std=c++17", "-Os", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-mllvm", "-enable-post-misched=0", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
             "-fno-gpu-flush-denormals-to-zero", f"-I{ROOT}/include", f"-I{SRC}/host", f"-I{SRC}"]
 
 

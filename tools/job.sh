@@ -1,7 +1,4 @@
 #!/bin/bash
-mkdir -p gpurun_out/r05w
-timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "scene or fuzz or run_rich or foreign or sparse or long_world" > gpurun_out/r05w/t.log 2>&1; echo "tests rc=$?"; tail -2 gpurun_out/r05w/t.log
-timeout -k 10 600 python3 tools/ab_fast.py "libcpuvox_gpu_base.so libcpuvox_gpu.so" --contexts 3 --latency 200 > gpurun_out/r05w/ab.txt 2>&1
-tail -7 gpurun_out/r05w/ab.txt
-timeout -k 10 600 python3 tools/ab_fast.py "libcpuvox_gpu_base.so libcpuvox_gpu.so" --contexts 2 --width 3840 --height 2160 --frames 64 > gpurun_out/r05w/ab4k.txt 2>&1
-tail -3 gpurun_out/r05w/ab4k.txt
+mkdir -p gpurun_out/r05x
+timeout -k 10 900 python3 tools/ab_fast.py "libcpuvox_gpu.so libcpuvox_gpu_minreg.so libcpuvox_gpu_maxocc.so libcpuvox_gpu_ilp_postra.so" --contexts 3 --latency 100 > gpurun_out/r05x/flags2.txt 2>&1
+tail -11 gpurun_out/r05x/flags2.txt
