@@ -1,8 +1,5 @@
 #!/bin/bash
-mkdir -p gpurun_out/r05y
-sha256sum cpuvox_amd/libcpuvox_gpu.so | cut -c1-16
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/r05y/gputests.log 2>&1; echo "tests rc=$?"; tail -2 gpurun_out/r05y/gputests.log
-timeout -k 10 1000 python3 tools/soak.py 2500 > gpurun_out/r05y/soak.txt 2>&1; tail -1 gpurun_out/r05y/soak.txt
-timeout -k 10 600 python3 tools/soak.py bench > gpurun_out/r05y/soak_bench.txt 2>&1; tail -1 gpurun_out/r05y/soak_bench.txt
-bash tools/profile_round.sh r05 > gpurun_out/r05y/profile.log 2>&1; tail -1 gpurun_out/r05y/profile.log | cut -c1-100
-sha256sum cpuvox_amd/libcpuvox_gpu.so | cut -c1-16
+mkdir -p gpurun_out/r05z2
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/r05z2/gputests.log 2>&1; echo "tests rc=$?"; tail -2 gpurun_out/r05z2/gputests.log
+for i in 1 2; do timeout -k 10 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-seconds 0 --latency-frames 200 > gpurun_out/r05z2/bench$i.json 2> gpurun_out/r05z2/bench$i.err; python3 -c "
+import json;d=json.load(open('gpurun_out/r05z2/bench$i.json'));print(d['value'],d['ms_per_step'],d['roofline']['kernel_ms_avg'],d['latency']['ms'],d['latency']['pipelined_2deep']['ms'],d.get('parity_checked'))"; done
