@@ -1,5 +1,8 @@
 #!/bin/bash
-mkdir -p gpurun_out/r05z2
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/r05z2/gputests.log 2>&1; echo "tests rc=$?"; tail -2 gpurun_out/r05z2/gputests.log
-for i in 1 2; do timeout -k 10 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-seconds 0 --latency-frames 200 > gpurun_out/r05z2/bench$i.json 2> gpurun_out/r05z2/bench$i.err; python3 -c "
-import json;d=json.load(open('gpurun_out/r05z2/bench$i.json'));print(d['value'],d['ms_per_step'],d['roofline']['kernel_ms_avg'],d['latency']['ms'],d['latency']['pipelined_2deep']['ms'],d.get('parity_checked'))"; done
+mkdir -p gpurun_out/r05z3
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "scene or fuzz or run_rich or foreign or sparse or long_world" > gpurun_out/r05z3/t.log 2>&1; echo "tests rc=$?"; tail -2 gpurun_out/r05z3/t.log
+timeout -k 10 600 python3 tools/section_counts.py 256 > gpurun_out/r05z3/counts.txt 2>&1; sed -n 3,9p gpurun_out/r05z3/counts.txt
+timeout -k 10 600 python3 tools/ab_fast.py "libcpuvox_gpu_base.so libcpuvox_gpu.so" --contexts 3 --latency 200 > gpurun_out/r05z3/ab.txt 2>&1
+tail -7 gpurun_out/r05z3/ab.txt
+timeout -k 10 600 python3 tools/ab_fast.py "libcpuvox_gpu_base.so libcpuvox_gpu.so" --contexts 2 --width 3840 --height 2160 --frames 64 > gpurun_out/r05z3/ab4k.txt 2>&1
+tail -3 gpurun_out/r05z3/ab4k.txt
