@@ -37,8 +37,8 @@ def _cheap_row(y, bx, by, uvax, uvbx, uvay, uvby, k1, k2):
         rd = np.where(np.abs(d) <= F(2.0 ** 100), _rcp(d, k1), F(np.nan)).astype(F)
         a1, a2 = (uvbx - uvax).astype(F), (uvby - uvay).astype(F)
         k = F(40.0 * 2.0 ** -24)
-        a1s = (k * (np.abs(uvax) + np.abs(uvbx)).astype(F)).astype(F)
-        a2s = (k * (np.abs(uvay) + np.abs(uvby)).astype(F)).astype(F)
+        a1s = (k * np.abs(a1)).astype(F)
+        a2s = (k * np.abs(a2)).astype(F)
         bxs = _fma(np.full_like(y, k), np.abs(uvax), np.full_like(y, F(2.0 ** -140)))
         bys = (k * np.abs(uvay)).astype(F)
         n = (y - bx).astype(F)
