@@ -53,7 +53,7 @@ def _cheap_row(y, bx, by, uvax, uvbx, uvay, uvby, k1, k2):
     return uq, certain
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
 def test_certain_rows_equal_the_reference_rows_for_any_one_ulp_reciprocal(seed):
     rng = np.random.default_rng(seed)
     n = 400_000
@@ -63,6 +63,10 @@ def test_certain_rows_equal_the_reference_rows_for_any_one_ulp_reciprocal(seed):
     y = np.rint(rng.uniform(bx - 1.0, by + 1.0)).clip(-2, 16385)
     zb = np.exp(rng.uniform(np.log(0.06), np.log(6000.0), n))
     zt = zb * np.exp(rng.uniform(-1.5, 1.5, n))
+    if seed == 4:  # a level camera: both ends at (nearly) the same depth, uvB.x - uvA.x cancels
+        zt = zb * (1.0 + rng.uniform(-1e-4, 1e-4, n) * rng.integers(0, 2, n))
+    if seed == 5:  # ends far apart in depth
+        zt = zb * np.exp(rng.uniform(-4.0, 4.0, n))
     ua = np.rint(np.exp(rng.uniform(0.0, np.log(600.0), n)))
     # a third of the samples: the run length chosen so that the row lands next to an integer for this pixel (where the floor is decided)
     t = np.clip((y - bx) / span, 0.0, 1.0)
@@ -73,7 +77,7 @@ def test_certain_rows_equal_the_reference_rows_for_any_one_ulp_reciprocal(seed):
     y, bx, by = y.astype(F), bx.astype(F), by.astype(F)
     uvax, uvbx = (F(1.0) / zb.astype(F)).astype(F), (F(1.0) / zt.astype(F)).astype(F)
     uvay, uvby = (ua.astype(F) / zb.astype(F)).astype(F), np.zeros(n, dtype=F)
-    if seed == 2:  # the swapped order (:496-499)
+    if seed in (2, 6):  # the swapped order (:496-499)
         uvax, uvbx, uvay, uvby = uvbx, uvax, uvby, uvay
     exact = _exact_row(y, bx, by, uvax, uvbx, uvay, uvby)
     certain_any = np.zeros(n, dtype=bool)
