@@ -1,7 +1,9 @@
 #!/bin/bash
-mkdir -p gpurun_out/r05z4
-timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "cheap or scene or fuzz or run_rich or foreign or sparse or long_world" > gpurun_out/r05z4/t.log 2>&1; echo "tests rc=$?"; tail -2 gpurun_out/r05z4/t.log; grep -n "^E  *Assert" gpurun_out/r05z4/t.log | cut -c1-300
-timeout -k 10 600 python3 tools/ab_fast.py "libcpuvox_gpu_base.so libcpuvox_gpu.so" --contexts 3 --latency 200 > gpurun_out/r05z4/ab.txt 2>&1
-tail -7 gpurun_out/r05z4/ab.txt
-timeout -k 10 600 python3 tools/ab_fast.py "libcpuvox_gpu_base.so libcpuvox_gpu.so" --contexts 2 --width 3840 --height 2160 --frames 64 > gpurun_out/r05z4/ab4k.txt 2>&1
-tail -3 gpurun_out/r05z4/ab4k.txt
+# scratch job script of the round (what `gpurun -- 'bash tools/job.sh'` last ran for the committed artefacts): GPU tests, parity soaks, the profile collection
+mkdir -p gpurun_out/final
+sha256sum cpuvox_amd/libcpuvox_gpu.so | cut -c1-16
+python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/final/gputests.log 2>&1; echo "tests rc=$?"; tail -2 gpurun_out/final/gputests.log
+timeout -k 10 1000 python3 tools/soak.py 2500 > gpurun_out/final/soak.txt 2>&1; tail -1 gpurun_out/final/soak.txt
+timeout -k 10 600 python3 tools/soak.py bench > gpurun_out/final/soak_bench.txt 2>&1; tail -1 gpurun_out/final/soak_bench.txt
+bash tools/profile_round.sh r05 > gpurun_out/final/profile.log 2>&1; tail -1 gpurun_out/final/profile.log | cut -c1-100
