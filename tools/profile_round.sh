@@ -23,8 +23,10 @@ timeout 900 python3 "$R/bench.py" --gpus 1 $DRV --pmc-csv "$OUT/pmc_render_kerne
 bash "$R/tools/pmc_stalls.sh" libcpuvox_gpu.so > "$OUT/sq_counters.txt" 2>&1
 bash "$R/tools/pmc_insts.sh" libcpuvox_gpu.so >> "$OUT/sq_counters.txt" 2>&1
 # 5. the 4K configurations (BASELINE.json configs 4 and 5 on one GPU): their own stamped traffic counters, then the bench line WITH the CPU leg (parity_checked)
-C4="--frames 128 --steps 4 --warmup 1 --width 3840 --height 2160"
-C5="--frames 64 --steps 4 --warmup 1 --width 3840 --height 2160 --world proc4096 --lod-error 4"
+# (256 frames per launch: ~2 - 3 M rays, like the 512 frames of the 1080p default; with the 128 / 64 frames of the round's first collections the launches were too short --
+# config 5 gains 10 % from 64 -> 256 frames, config 4 2 % from 128 -> 256, the 1080p default 1 % from 512 -> 1024)
+C4="--frames 256 --steps 4 --warmup 1 --width 3840 --height 2160"
+C5="--frames 256 --steps 4 --warmup 1 --width 3840 --height 2160 --world proc4096 --lod-error 4"
 PMC_ONLY_TRAFFIC=1 bash "$R/tools/pmc_passes.sh" "$OUT/pmc4" --cpu-seconds 0 --latency-frames 0 $C4 > "$OUT/pmc4_passes.log" 2>&1
 python3 "$R/tools/pmc_aggregate.py" "$OUT/pmc4" "render_kernel<false>" --cpu-seconds 0 --latency-frames 0 $C4 > "$OUT/pmc_render_kernel_config4.csv"
 timeout 900 python3 "$R/bench.py" --cpu-seconds 15 --latency-frames 0 $C4 --pmc-csv "$OUT/pmc_render_kernel_config4.csv" > "$OUT/bench_config4_1gpu.json" 2> "$OUT/bench_config4.err"
