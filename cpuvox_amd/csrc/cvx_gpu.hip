@@ -18,6 +18,7 @@
 #include "cvx_context.h"
 #include "cpuvox_gpu_diag.h"
 #include "cvx_kernels.h"
+#include "cvx_lone.h"
 
 namespace {
 std::string g_createError; // cvx_last_error(NULL)
@@ -431,6 +432,10 @@ int Launch(cvx_context *ctx, int frameCount, int flags)
 		dim3 grid((unsigned)nTiles), block(CVX_WAVE);
 		if (ctx->countersEnabled) {
 			hipLaunchKernelGGL((cvxk::render_kernel<true>), grid, block, ldsBytes, ctx->stream, ctx->devFrames, ctx->devTiles, ctx->devWorld, ctx->devCounters);
+		} else if (ctx->launchLone == 1) { // one wave per ray, lanes = columns (cvx_lone.h): the single interactive frame
+			hipLaunchKernelGGL((cvxk::lone_kernel<false>), grid, block, 0, ctx->stream, ctx->devFrames, ctx->devTiles, ctx->devWorld);
+		} else if (ctx->launchLone == 2) { // ... windows of more than 2048 pixels (4K)
+			hipLaunchKernelGGL((cvxk::lone_kernel<true>), grid, block, 0, ctx->stream, ctx->devFrames, ctx->devTiles, ctx->devWorld);
 		} else {
 			hipLaunchKernelGGL((cvxk::render_kernel<false>), grid, block, ldsBytes, ctx->stream, ctx->devFrames, ctx->devTiles, ctx->devWorld, ctx->devCounters);
 		}
@@ -505,6 +510,13 @@ int cvx_create(int device, cvx_context **out)
 		if (const char *v = std::getenv("CVX_TILE_COST_PIXELS")) { // diagnostics
 			const float w = (float)std::atof(v);
 			if (w >= 0.f && w <= 100.f) { ctx->tileCostPixelWeight = w; }
+		}
+		if (const char *v = std::getenv("CVX_LONE")) { // diagnostics: 0 = never the one-wave-per-ray kernel, 1 = always (whatever the batch size), unset = by the wave budget
+			ctx->loneMode = std::atoi(v) != 0 ? 2 : 0;
+		}
+		if (const char *v = std::getenv("CVX_LONE_BUDGET")) { // diagnostics: the largest launch (in rays) the one-wave-per-ray kernel is chosen for
+			const int w = std::atoi(v);
+			if (w >= 0) { ctx->loneWaveBudget = w; }
 		}
 		if (const char *v = std::getenv("CVX_MIN_MASK_WORDS")) {
 			const int w = std::atoi(v);
@@ -739,6 +751,26 @@ int DrawBatch(cvx_context *ctx, int frameCount, const cvx_segment_data *segments
 		// need, so narrower waves finish sooner; with few waves there are idle SIMDs to run them on (1 frame: 6.7 -> 4.0 ms at
 		// 2 rays per wave, 16 frames: 8.6 -> 6.3 ms at 16).  Once the chip is full the fixed per-wave part dominates and splitting loses (256
 		// frames: x1.6 slower at split 2), hence the wave budget.
+		// A launch of few rays (the reference's call pattern: ONE frame per blocking call, RenderManager.cs:358-363) goes to the latency kernel
+		// (cvx_lone.h): one wave per RAY, its lanes the ray's next 64 columns.  Its mask lives in one or two vector registers: windows of up to 4096 pixels.
+		ctx->launchLone = 0;
+		if (!ctx->countersEnabled && ctx->maskWordsNeeded <= 2 * CVX_WAVE && (ctx->loneMode == 2 || (ctx->loneMode == 1 && n * (size_t)CVX_WAVE <= (size_t)ctx->loneWaveBudget)) && n > 0) {
+			std::vector<DevTile> rays;
+			rays.reserve(n * (size_t)CVX_WAVE);
+			for (size_t i = 0; i < n; i++) {
+				DevTile t = ctx->hostTiles[order[i]];
+				const DevSegment &S = ctx->hostFrames[(size_t)t.frame].seg[t.seg];
+				const int raysOfTile = std::min(CVX_WAVE, S.rayCount - t.tileInSeg * CVX_WAVE);
+				for (int k = 0; k < raysOfTile; k++) {
+					t.lanes = k | (1 << 8) | (6 << 16); // (the sub-tile form of one ray: firstLane | laneCount << 8 | dupShift << 16)
+					rays.push_back(t);
+				}
+			}
+			ctx->launchLone = ctx->maskWordsNeeded > CVX_WAVE ? 2 : 1;
+			ctx->ldsWordsNeeded = 0;
+			ctx->hostTiles.swap(rays);
+			return Launch(ctx, frameCount, flags);
+		}
 		int split = 1;
 		while (split < CVX_WAVE && n * (size_t)split * 2 <= (size_t)ctx->splitWaveBudget) { split *= 2; }
 		if (ctx->forcedSplit > 0) { split = ctx->forcedSplit; }
@@ -1263,6 +1295,20 @@ int cvx_copy_rows(cvx_context *ctx, void *hipStream, int toPacked, int64_t spanC
 	CVX_HIP(ctx, hipGetLastError());
 	return CVX_OK;
 }
+
+#ifdef CVX_LONE_STATS /* diagnostic variant only (tools/lone_stats.py): event counts of the latency kernel, accumulated over all launches */
+int cvx_debug_lone_stats(uint64_t out[32], int reset)
+{
+	unsigned long long tmp[32];
+	if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(tmp, HIP_SYMBOL(cvxk::g_loneStats), sizeof tmp) != hipSuccess) { return CVX_ERR_HIP; }
+	for (int i = 0; i < 32; i++) { out[i] = tmp[i]; }
+	if (reset) {
+		std::memset(tmp, 0, sizeof tmp);
+		if (hipMemcpyToSymbol(HIP_SYMBOL(cvxk::g_loneStats), tmp, sizeof tmp) != hipSuccess) { return CVX_ERR_HIP; }
+	}
+	return CVX_OK;
+}
+#endif
 
 #if defined(CVX_EXPERIMENTS) || defined(CVX_PROFILE_SECTIONS) /* include/cpuvox_gpu_diag.h: not in the product library */
 int cvx_debug_occupancy(cvx_context *ctx, int64_t ldsBytes, int *blocksPerCU)

@@ -1,0 +1,823 @@
+// cvx_lone.h -- the LATENCY kernel of libcpuvox_gpu (gfx950 / CDNA4, wave64): one wavefront per RAY, lanes = the next 64 COLUMNS of that ray.
+//
+// The reference's caller issues one blocking DrawSegments per frame (UnityManager.cs:182, RenderManager.cs:358-363): 6000 rays at 1080p on a chip with
+// 1024 SIMDs.  render_kernel (cvx_kernels.h, lanes = rays) is built for batches; for a single frame every wave ends up with one or two rays and
+// executes the whole column loop -- DDA step, cull, clip, run projection, pixel loops -- once per column with 62 idle (duplicate) lanes.  A frame then
+// takes as long as the instruction stream of its longest ray.
+//
+// Here the 64 lanes of a wave hold 64 CONSECUTIVE COLUMNS of one ray (a "window"), and everything of ExecuteRay (DrawSegmentRayJob.cs:195-620) that
+// does not depend on the ray's evolving pixel state is computed for the whole window at once:
+//   * the DDA sequence (SegmentDDAData.Step, SegmentDDAData.cs:135-150): the wave runs the ray's DDA 64 steps ahead (the reference's own additions in
+//     the reference's own order: wave-uniform), lane k latches the state of step k;
+//   * the 64 column records of the window: ONE round trip to memory instead of one per column;
+//   * the Q corners (:289-293) and, for each of the up to three solid runs a record holds, the whole side / face projection (:478-502, :566-578): near
+//     clip, the six quotients, the rounded pixel bounds and the texture generators -- pure functions of the column's two distances and the run's span;
+//   * the colour of each run's top / bottom face (:553,560).
+// What remains serial is the part that reads and writes the ray's state -- the seen mask, nextFreePixelMin / Max, frustumBounds, the cached frustum
+// directions (:214-221) -- and it is organised by EVENTS, not by columns:
+//   * while the frustum directions are valid (no pixel written since the last clip, :261), the cull (:261-281) and the overlap tests of all runs
+//     (:461-475, :505, :581) are evaluated for ALL remaining columns of the window in one pass; a ballot + s_ff1 finds the first column that can
+//     touch the state; the columns before it provably change nothing (they are culled, or none of their runs overlaps [nextFreePixelMin, Max]);
+//   * that column is processed exactly as the reference does, run by run, with wave-uniform scalars read from its lane (v_readlane);
+//   * after a pixel write the directions are invalid (:522,598): the next non-empty column clips (:295-422) -- computed in the column's own lane --
+//     and the pass over the remaining columns is repeated with the new directions.
+// The seen mask (:208) is ONE WORD PER LANE in a vector register (two for windows of more than 2048 pixels): horizon scans (:407-414, :678-692) are a
+// ballot over "my word has an unseen bit in range" + s_ff1 / s_flbit + one v_readlane; the pixel loops (:519-533, :595-603) run with lane = PIXEL (64
+// pixels per trip); the mask clear is free and the skybox pass (:699-716) is lane = word.
+//
+// Arithmetic: the SAME device functions as render_kernel (cvx_kernels.h) on the same values in the same order -- the contract (IEEE binary32, no
+// contraction, x86 cvttss2si) is shared; results are bit-identical to render_kernel and to the CPU oracle (tests/test_gpu_parity.py, tools/soak.py).
+#pragma once
+
+#include "cvx_kernels.h"
+
+namespace cvxk {
+
+typedef unsigned long long lanemask_t;
+
+// diagnostic build only (-DCVX_LONE_STATS, tools/lone_stats.py): how often each part of the latency kernel runs per launch
+#ifdef CVX_LONE_MARK /* static accounting only (tools/lone_static.py): comment markers in the assembly around the kernel's parts */
+#define CVX_LMARK(name) asm volatile("; LMARK " name ::: "memory")
+#else
+#define CVX_LMARK(name) ((void)0)
+#endif
+#ifdef CVX_LONE_STATS
+__device__ unsigned long long g_loneStats[32];
+#define CVX_LSTAT(n) (stat_[n]++)
+#define CVX_LSTAT_ADD(n, v) (stat_[n] += (unsigned int)(v))
+#else
+#define CVX_LSTAT(n) ((void)0)
+#define CVX_LSTAT_ADD(n, v) ((void)0)
+#endif
+
+__device__ __forceinline__ float rlf(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ int rli(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ uint32_t rlu(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+__device__ __forceinline__ lanemask_t lanes_from(int l) { return ~0ull << l; } // lanes >= l (l in 0..63)
+// A wave-uniform value the compiler cannot PROVE uniform (the result of an inline-asm instruction -- f2i, hw_min -- counts as divergent, and everything
+// computed from it, and every branch on that: exec-mask loops instead of scalar branches): read from the first lane, it is uniform by construction.
+__device__ __forceinline__ float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// bits of mask word `w` (absolute word index) that fall inside the pixel range [lo, hi]; any w, lo, hi (empty ranges give 0)
+__device__ __forceinline__ uint32_t range_mask_any(int w, int lo, int hi)
+{
+	const int base = w << 5;
+	const int a = max(lo - base, 0), b = min(hi - base, 31); // first / last bit of the word inside the range
+	const uint32_t m = (0xFFFFFFFFu << (a & 31)) & (0xFFFFFFFFu >> ((31 - b) & 31));
+	return a > b ? 0u : m;
+}
+
+// The ray's seen-pixel mask: word (wordBase + lane) in w0, word (wordBase + 64 + lane) in w1 (HI instances only)
+struct LoneSeen {
+	uint32_t w0, w1;
+	int wordBase, lane;
+};
+
+// first unseen pixel >= start, or omax + 1; start unchanged when start > omax (the reference's while loop at :407 / :678 does not run then)
+template <bool HI>
+__device__ __forceinline__ int lone_scan_up(const LoneSeen &s, int start, int omax)
+{
+	if (start > omax) { return start; }
+	const uint32_t m0 = ~s.w0 & range_mask_any(s.wordBase + s.lane, start, omax);
+	const lanemask_t b0 = __ballot(m0 != 0u);
+	if (b0 != 0ull) {
+		const int l = __ffsll((long long)b0) - 1;
+		return ((s.wordBase + l) << 5) + (__ffs((int)rlu(m0, l)) - 1);
+	}
+	if (HI) {
+		const uint32_t m1 = ~s.w1 & range_mask_any(s.wordBase + 64 + s.lane, start, omax);
+		const lanemask_t b1 = __ballot(m1 != 0u);
+		if (b1 != 0ull) {
+			const int l = __ffsll((long long)b1) - 1;
+			return ((s.wordBase + 64 + l) << 5) + (__ffs((int)rlu(m1, l)) - 1);
+		}
+	}
+	return omax + 1;
+}
+
+// last unseen pixel <= start, or omin - 1; start unchanged when start < omin (:413 / :690)
+template <bool HI>
+__device__ __forceinline__ int lone_scan_down(const LoneSeen &s, int start, int omin)
+{
+	if (start < omin) { return start; }
+	if (HI) {
+		const uint32_t m1 = ~s.w1 & range_mask_any(s.wordBase + 64 + s.lane, omin, start);
+		const lanemask_t b1 = __ballot(m1 != 0u);
+		if (b1 != 0ull) {
+			const int l = 63 - __clzll((long long)b1);
+			return ((s.wordBase + 64 + l) << 5) + (31 - __clz((int)rlu(m1, l)));
+		}
+	}
+	const uint32_t m0 = ~s.w0 & range_mask_any(s.wordBase + s.lane, omin, start);
+	const lanemask_t b0 = __ballot(m0 != 0u);
+	if (b0 != 0ull) {
+		const int l = 63 - __clzll((long long)b0);
+		return ((s.wordBase + l) << 5) + (31 - __clz((int)rlu(m0, l)));
+	}
+	return omin - 1;
+}
+
+// ReducePixelHorizon, DrawSegmentRayJob.cs:660-697 (the scalar form of reduce_pixel_horizon in cvx_kernels.h: every operand is wave-uniform)
+template <bool HI>
+__device__ __forceinline__ void lone_reduce_pixel_horizon(const LoneSeen &s, int omin, int omax, int &rbMin, int &rbMax, int &nfMin, int &nfMax, float &frustumBoundsMin,
+                                                          float &frustumBoundsMax)
+{
+	const bool raiseMin = rbMin <= nfMin && rbMax >= nfMin;
+	rbMin = max(rbMin, nfMin);
+	if (raiseMin) {
+		nfMin = lone_scan_up<HI>(s, rbMax + 1, omax);
+		frustumBoundsMin = (float)nfMin - 0.501f;
+	}
+	const bool lowerMax = rbMax >= nfMax && rbMin <= nfMax;
+	rbMax = min(rbMax, nfMax);
+	if (lowerMax) {
+		nfMax = lone_scan_down<HI>(s, rbMin - 1, omin);
+		frustumBoundsMax = (float)nfMax + 0.501f;
+	}
+}
+
+// mask word `i` (0 .. 127, relative to wordBase) as a wave-uniform scalar; words the instance does not hold read as "all seen"
+template <bool HI>
+__device__ __forceinline__ uint32_t lone_word(const LoneSeen &s, int i)
+{
+	const uint32_t a = rlu(s.w0, i & 63);
+	if (!HI) { return i < 64 ? a : 0xFFFFFFFFu; }
+	const uint32_t b = rlu(s.w1, i & 63);
+	return i < 64 ? a : (i < 128 ? b : 0xFFFFFFFFu);
+}
+
+// the pixels yb .. yb + 63 that are NOT yet seen, as a lane mask (bit p = pixel yb + p); yb >= omin
+template <bool HI>
+__device__ __forceinline__ lanemask_t lone_unseen64(const LoneSeen &s, int yb)
+{
+	const int i = (yb >> 5) - s.wordBase, sh = yb & 31;
+	const unsigned long long a = lone_word<HI>(s, i), b = lone_word<HI>(s, i + 1), c = lone_word<HI>(s, i + 2);
+	const unsigned long long lo = (a | (b << 32)) >> sh, hi = (b | (c << 32)) >> sh;
+	return ~((lo & 0xFFFFFFFFull) | (hi << 32));
+}
+
+// marks the pixels [lo, hi] as seen (every word at once: lane = word)
+template <bool HI>
+__device__ __forceinline__ void lone_mark(LoneSeen &s, int lo, int hi)
+{
+	s.w0 |= range_mask_any(s.wordBase + s.lane, lo, hi);
+	if (HI) { s.w1 |= range_mask_any(s.wordBase + 64 + s.lane, lo, hi); }
+}
+
+// ---- projection of one solid run of one column: everything of :478-502 (side) and :566-578 (face) that depends on nothing but the column's
+// corners and the run's span.  The same operations in the same order as drawColumn (cvx_kernels.h); called once per run index for the 64 columns
+// of a window (every operand per lane), and with wave-uniform operands for the columns of the run list.
+struct RunProj {
+	float boundsX, boundsY, uvAx, uvBx, uvAy, uvBy; // the side's two ends after the swap of :496-499 (rayBufferBoundsFloat, uvA, uvB)
+	int rbMinS, rbMaxS;                             // :501-502
+	int rbMinF, rbMaxF;                             // the face's pixel bounds, ordered (:570-578)
+	bool sideVisible, faceNear;                     // the near-plane clips (CameraData.cs:124-157) left something of the side / the face
+	bool faceTop, faceBottom;                       // :549-565 (which face the camera can see; `wanted` also needs the world bounds)
+};
+
+__device__ __forceinline__ RunProj project_run(f3 camSpaceMinLast, f3 camSpaceMaxLast, f3 camSpaceMinNext, f3 camSpaceMaxNext, float elementBoundsMin, float elementBoundsMax,
+                                               int elementLength, float cameraPosYNormalized, float invWorldMaxY)
+{
+	RunProj P;
+	const float portionBottom = elementBoundsMin * invWorldMaxY;
+	const float portionTop = elementBoundsMax * invWorldMaxY;
+	f3 camSpaceFrontBottom = f3_lerp(camSpaceMinLast, camSpaceMaxLast, portionBottom);
+	f3 camSpaceFrontTop = f3_lerp(camSpaceMinLast, camSpaceMaxLast, portionTop);
+	const bool faceTop = portionTop < cameraPosYNormalized;
+	const bool faceBottom = ((int)!faceTop & (int)(portionBottom > cameraPosYNormalized)) != 0;
+	f3 secA = f3_lerp(camSpaceMinNext, camSpaceMaxNext, faceTop ? portionTop : portionBottom);
+	float frontBottomQuotient, frontTopQuotient, secBQuotient;
+	bool faceVisible = true;
+	float uA = (float)elementLength;
+	float uB = 0.0f;
+	bool visible = true;
+	float uvAx, uvAy, uvBx, uvBy;
+	{
+		const Recip rb = recip_safe(camSpaceFrontBottom.z), rt = recip_safe(camSpaceFrontTop.z);
+		uvAx = quot_safe(1.0f, rb);
+		uvAy = quot_safe(uA, rb);
+		frontBottomQuotient = quot_safe(camSpaceFrontBottom.x, rb);
+		uvBx = quot_safe(1.0f, rt);
+		uvBy = __int_as_float(__float_as_int(camSpaceFrontTop.z) & (int)0x80000000); // +0 / z
+		frontTopQuotient = quot_safe(camSpaceFrontTop.x, rt);
+	}
+	secBQuotient = faceTop ? frontTopQuotient : frontBottomQuotient;
+	const bool ordinary = ((int)!(camSpaceFrontBottom.y <= 0.0f) & (int)!(camSpaceFrontTop.y <= 0.0f) & (int)!(secA.y <= 0.0f) & (int)div_safe(camSpaceFrontBottom.z) & (int)div_safe(camSpaceFrontTop.z) &
+	                       (int)div_safe(camSpaceFrontBottom.x) & (int)div_safe(camSpaceFrontTop.x)) != 0;
+	if (CVX_RARE(!ordinary)) {
+		if (camSpaceFrontBottom.y <= 0.0f) {
+			if (camSpaceFrontTop.y <= 0.0f) {
+				visible = false;
+			} else {
+				float v = camSpaceFrontTop.y / (camSpaceFrontTop.y - camSpaceFrontBottom.y);
+				camSpaceFrontBottom = f3_lerp(camSpaceFrontTop, camSpaceFrontBottom, v);
+				uA = m_lerp(uB, uA, v);
+			}
+		} else if (camSpaceFrontTop.y <= 0.0f) {
+			float v = camSpaceFrontBottom.y / (camSpaceFrontBottom.y - camSpaceFrontTop.y);
+			camSpaceFrontTop = f3_lerp(camSpaceFrontBottom, camSpaceFrontTop, v);
+			uB = m_lerp(uA, uB, v);
+		}
+		uvAx = 1.0f / camSpaceFrontBottom.z;
+		uvAy = uA / camSpaceFrontBottom.z;
+		uvBx = 1.0f / camSpaceFrontTop.z;
+		uvBy = uB / camSpaceFrontTop.z;
+		frontBottomQuotient = camSpaceFrontBottom.x / camSpaceFrontBottom.z;
+		frontTopQuotient = camSpaceFrontTop.x / camSpaceFrontTop.z;
+		f3 secB = faceTop ? camSpaceFrontTop : camSpaceFrontBottom;
+		if (secA.y <= 0.0f) {
+			if (secB.y <= 0.0f) {
+				faceVisible = false;
+			} else {
+				float v = secB.y / (secB.y - secA.y);
+				secA = f3_lerp(secB, secA, v);
+			}
+		} else if (secB.y <= 0.0f) {
+			float v = secA.y / (secA.y - secB.y);
+			secB = f3_lerp(secA, secB, v);
+		}
+		secBQuotient = secB.x / secB.z;
+	}
+	{
+		float boundsX = frontBottomQuotient;
+		float boundsY = frontTopQuotient;
+		const bool sw = boundsX > boundsY;
+		P.boundsX = sw ? boundsY : boundsX;
+		P.boundsY = sw ? boundsX : boundsY;
+		P.uvAx = sw ? uvBx : uvAx;
+		P.uvBx = sw ? uvAx : uvBx;
+		P.uvAy = sw ? uvBy : uvAy;
+		P.uvBy = sw ? uvAy : uvBy;
+		P.rbMinS = f2i(rintf(P.boundsX));
+		P.rbMaxS = f2i(rintf(P.boundsY));
+	}
+	{
+		const float bx = rintf(secA.x / secA.z);
+		const float by = rintf(secBQuotient);
+		const int a = f2i(bx), b = f2i(by);
+		P.rbMinF = min(a, b);
+		P.rbMaxF = max(a, b);
+	}
+	P.sideVisible = visible;
+	P.faceNear = faceVisible;
+	P.faceTop = faceTop;
+	P.faceBottom = faceBottom;
+	return P;
+}
+
+// flag bits of a lane's `flags` word, per run r (0 .. 2): bit r * 8 + ...
+#define CVX_LF_EXISTS 1u
+#define CVX_LF_SIDE 2u
+#define CVX_LF_FACENEAR 4u
+#define CVX_LF_FACETOP 8u
+#define CVX_LF_FACEBOTTOM 16u
+#define CVX_LF_LISTED (1u << 24) /* the column's runs live in the run list: processed with wave-uniform operands when its turn comes */
+
+// ---------------------------------------------------------------------------
+// One ray: TraceToFirstColumnJob + ExecuteRay by one wave.
+// ---------------------------------------------------------------------------
+template <int DIR, bool HI>
+__device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegment &S, const DevWorld *__restrict__ world, int planeRayIndex, gptr_tile tileOut, uint32_t laneByteOff,
+                                               LoneSeen &seen, unsigned int *stat_)
+{
+	(void)stat_;
+	const int lane = seen.lane;
+	const int omin = S.omin, omax = S.omax;
+	const float farClip = F.farClip;
+	const float posY = F.posY;
+
+	// ---- DDASetupJob.Execute, :58-76 (wave-uniform)
+	DDA ray;
+	{
+		float endRayLerp = (float)planeRayIndex / (float)S.rayCount;
+		float dx = m_lerp(S.rayMinX, S.rayMaxX, endRayLerp);
+		float dz = m_lerp(S.rayMinZ, S.rayMaxZ, endRayLerp);
+		float r = 1.0f / sqrtf(dx * dx + dz * dz);
+		dda_init(ray, F.posX, F.posZ, r * dx, r * dz);
+	}
+	const bool dirXNonNegative = ray.dirX >= 0.0f, dirZNonNegative = ray.dirZ >= 0.0f;
+
+	// ---- TraceToFirstColumnJob.Execute, :95-143
+	int lod = 0;
+	float lodMax = F.lod[0];
+	const int dimX = world->dimX, dimZ = world->dimZ;
+	if (ray.px < 0 || ray.pz < 0 || ray.px >= dimX || ray.pz >= dimZ) {
+		if (!dda_step_to_world_intersection(ray, (float)dimX, (float)dimZ)) {
+			return; // WriteSkyboxFull
+		}
+		while (ray.distLast >= lodMax) {
+			dda_next_lod(ray, 1 << lod, dirXNonNegative, dirZNonNegative);
+			lod++;
+			{ const float next_ = F.lod[min(lod, 5)]; lodMax = lod < 5 ? next_ : __builtin_inff(); }
+		}
+		if (m_min(ray.tMaxX, ray.tMaxZ) >= farClip) {
+			return; // WriteSkyboxFull
+		}
+	}
+
+	// (the ray's state is wave-uniform: say so, see uni())
+	ray.px = uni(ray.px); ray.pz = uni(ray.pz); ray.sx = uni(ray.sx); ray.sz = uni(ray.sz);
+	ray.startX = uni(ray.startX); ray.startZ = uni(ray.startZ); ray.dirX = uni(ray.dirX); ray.dirZ = uni(ray.dirZ);
+	ray.tDeltaX = uni(ray.tDeltaX); ray.tDeltaZ = uni(ray.tDeltaZ); ray.tMaxX = uni(ray.tMaxX); ray.tMaxZ = uni(ray.tMaxZ);
+	ray.distLast = uni(ray.distLast); ray.distNext = uni(ray.distNext);
+	lod = uni(lod);
+	lodMax = uni(lodMax);
+
+	// ---- ExecuteRay, :195-620
+	int voxelScale = 1 << lod;
+	DevWorldLevel L = world->level[lod];
+	const gptr_arena arena = (gptr_arena)world->arena;
+	const int maskX = world->maskX, maskZ = world->maskZ;
+	const int worldMaxYInt = world->dimY;
+	const float worldMaxY = (float)worldMaxYInt;
+	const float cameraPosYNormalized = posY / worldMaxY;
+	const float invWorldMaxY = 1.0f / worldMaxY;
+
+	int nextFreePixelMin = omin;
+	int nextFreePixelMax = omax;
+	float frustumBoundsMin = (float)nextFreePixelMin - 0.501f;
+	float frustumBoundsMax = (float)nextFreePixelMax + 0.501f;
+	float frustumDirMaxWorld = CVX_FLOAT_EPSILON;
+	float frustumDirMinWorld = CVX_FLOAT_EPSILON;
+
+	f3 planeStartBottom, planeStartTop, planeDir; // SetupProjectedPlaneParams, :622-651
+	{
+		const float *M = F.M;
+		const int r0 = S.axisMappedToY ? 1 : 0;
+		const float sx = ray.startX, sz = ray.startZ;
+		planeStartTop.x = M[0 + r0] * sx + M[4 + r0] * worldMaxY + M[8 + r0] * sz + M[12 + r0] * 1.0f;
+		planeStartTop.y = M[2] * sx + M[6] * worldMaxY + M[10] * sz + M[14] * 1.0f;
+		planeStartTop.z = M[3] * sx + M[7] * worldMaxY + M[11] * sz + M[15] * 1.0f;
+		planeStartBottom.x = M[0 + r0] * sx + M[4 + r0] * 0.0f + M[8 + r0] * sz + M[12 + r0] * 1.0f;
+		planeStartBottom.y = M[2] * sx + M[6] * 0.0f + M[10] * sz + M[14] * 1.0f;
+		planeStartBottom.z = M[3] * sx + M[7] * 0.0f + M[11] * sz + M[15] * 1.0f;
+		planeDir.x = M[0 + r0] * ray.dirX + M[4 + r0] * 0.0f + M[8 + r0] * ray.dirZ + M[12 + r0] * 0.0f;
+		planeDir.y = M[2] * ray.dirX + M[6] * 0.0f + M[10] * ray.dirZ + M[14] * 0.0f;
+		planeDir.z = M[3] * ray.dirX + M[7] * 0.0f + M[11] * ray.dirZ + M[15] * 0.0f;
+	}
+
+	// column 0: LOD check (:237-243), bounds test (World.GetVoxelColumn, World.cs:130-142)
+	if (ray.distLast >= lodMax) {
+		dda_next_lod(ray, voxelScale, dirXNonNegative, dirZNonNegative);
+		lod++;
+		voxelScale *= 2;
+		L = world->level[lod];
+		{ const float next_ = F.lod[min(lod, 5)]; lodMax = lod < 5 ? next_ : __builtin_inff(); }
+	}
+	if ((ray.px & maskX) != ray.px || (ray.pz & maskZ) != ray.pz) {
+		return; // out of world bounds -> WriteSkybox
+	}
+	// the column as ONE integer x * 65536 + z and what a step adds to it (ColumnCursor of cvx_kernels.h, without the record address: lanes compute their own)
+	int pos = ray.px * 65536 + ray.pz;
+	int posStepX = ray.sx * 65536, posStepZ = ray.sz;
+	const int outsideBits = ~((maskX << 16) | maskZ);
+	// A DDA walk is monotone in x and z: it leaves the world after at most dimX + dimZ columns; the cap only keeps a wave from spinning on non-finite camera data
+	int guardSteps = 2 * (dimX + dimZ + 16);
+
+	bool alive = true; // false: the ray is finished (every exit of the reference is WriteSkybox, which the caller does)
+	while (alive) {
+		// ================= the window: the ray's next (up to) 64 columns at this level =================
+		// Lane k latches the column the DDA stands on after k steps; the steps are the reference's (Step :135-150), wave-uniform.  The window ends early at
+		// the far clip / the world's edge (:613, :246: the ray ends after it) and at this level's LOD distance (:237-243: NextLOD, then the next window).
+		float wDistLast = 0.0f, wDistNext = 0.0f;
+		int wPos = 0;
+		int count = 0;
+		int endCode = 0; // 0: 64 columns, more at this level; 1: the ray ends after this window; 2: LOD boundary
+		for (int k = 0; k < CVX_WAVE; k++) {
+			const bool mine = lane == k;
+			CVX_LMARK("dda_begin");
+			wDistLast = mine ? ray.distLast : wDistLast;
+			wDistNext = mine ? ray.distNext : wDistNext;
+			wPos = mine ? pos : wPos;
+			count = k + 1;
+			{ // Step
+				const bool stepX = ray.tMaxX < ray.tMaxZ;
+				const float crossed = ray.distNext; // (the smaller tMax: see dda_step_cursor)
+				const float nextX = ray.tMaxX + ray.tDeltaX, nextZ = ray.tMaxZ + ray.tDeltaZ;
+				ray.tMaxX = stepX ? nextX : ray.tMaxX;
+				ray.tMaxZ = stepX ? ray.tMaxZ : nextZ;
+				pos += stepX ? posStepX : posStepZ;
+				ray.distLast = crossed;
+				ray.distNext = ray.tMaxX < ray.tMaxZ ? ray.tMaxX : ray.tMaxZ; // cmin(tMax) (:147): finite positive sums; the same compare picks the next step's axis
+			}
+			if (ray.distLast >= farClip || (pos & outsideBits) != 0) { endCode = 1; break; }
+			if (ray.distLast >= lodMax) { endCode = 2; break; }
+			CVX_LMARK("dda_end");
+		}
+		guardSteps -= count;
+		if (guardSteps <= 0) { endCode = 1; }
+		CVX_LSTAT(0);
+		CVX_LSTAT_ADD(1, count);
+
+		CVX_LMARK("winsetup_begin");
+		// ---- the window's records: one load per lane, all in flight together
+		const bool valid = lane < count;
+		uint4 rec = uint4{ 0u, 0u, 0u, 0u }; // (a lane without a column: the empty column's record)
+		if (valid) {
+			const int px = wPos >> 16, pz = wPos & 0xFFFF;
+			rec = ld4(arena, L.recordsOff + record_offset(px >> L.shift, pz >> L.shift, L.rowShift));
+		}
+		// :289-293 (per lane)
+		const f3 camSpaceMinLast = f3_madd(planeStartBottom, planeDir, wDistLast);
+		const f3 camSpaceMinNext = f3_madd(planeStartBottom, planeDir, wDistNext);
+		const f3 camSpaceMaxLast = f3_madd(planeStartTop, planeDir, wDistLast);
+		const f3 camSpaceMaxNext = f3_madd(planeStartTop, planeDir, wDistNext);
+
+		// ---- the runs of the records (cvx_device.h) and their projections
+		const bool nonEmpty = rec.x != 0u;
+		const bool listed = ((int)nonEmpty & (int)(rec.x < 0x40000000u)) != 0;
+		const int code = (int)(rec.x >> 30); // solid runs in the record (0 for empty and listed columns)
+		const lanemask_t nonEmptyMask = __ballot(nonEmpty);
+		const uint32_t colorsOff = L.elementsOff + (rec.x & 0x3FFFFFFFu) * 4u; // ColorPointer, World.cs:185
+		// run r = [runB[r], runT[r]] in LOD-0 voxels, RLEElement.Length and ColorsIndex (the lengths of the runs above)
+		int runB[3], runT[3], runLen[3], runCidx[3];
+		runB[0] = (int)(rec.w & 0xFFFFu);
+		runT[0] = (int)(rec.y >> 16);
+		runB[1] = (int)(rec.z & 0xFFFFu);
+		runT[1] = (int)(rec.w >> 16) + 1;
+		runB[2] = (int)(rec.y & 0xFFFFu);
+		runT[2] = (int)(rec.z >> 16) + 1;
+#pragma unroll
+		for (int r = 0; r < 3; r++) { runLen[r] = (runT[r] - runB[r]) >> lod; }
+		runCidx[0] = 0;
+		runCidx[1] = runLen[0];
+		runCidx[2] = runLen[0] + runLen[1];
+		RunProj P[3];
+		uint32_t faceColor[3];
+		uint32_t flags = listed ? CVX_LF_LISTED : 0u;
+#pragma unroll
+		for (int r = 0; r < 3; r++) {
+			const bool exists = r < code;
+			faceColor[r] = 0u;
+			P[r] = RunProj{};
+			if (r == 0 || __ballot(exists) != 0ull) { CVX_LSTAT(2); // (wave-uniform: a window without a second / third run anywhere skips their projections)
+				P[r] = project_run(camSpaceMinLast, camSpaceMaxLast, camSpaceMinNext, camSpaceMaxNext, (float)runB[r], (float)runT[r], runLen[r], cameraPosYNormalized, invWorldMaxY);
+				if (exists) {
+					// :553,560: the run's first colour for a top face, its last for a bottom face (read for every run: the address is a colour of this run either way)
+					faceColor[r] = ld_color(arena, colorsOff + ((uint32_t)(P[r].faceTop ? runCidx[r] : runCidx[r] + runLen[r] - 1) << L.colorShift));
+				}
+				const uint32_t f = (exists ? CVX_LF_EXISTS : 0u) | (P[r].sideVisible ? CVX_LF_SIDE : 0u) | (P[r].faceNear ? CVX_LF_FACENEAR : 0u) | (P[r].faceTop ? CVX_LF_FACETOP : 0u) |
+				                   (P[r].faceBottom ? CVX_LF_FACEBOTTOM : 0u);
+				flags |= (exists ? f : 0u) << (r * 8);
+			}
+		}
+
+		CVX_LMARK("winsetup_end");
+		float wbMin = 0.0f, wbMax = worldMaxY; // worldBoundsMin / Max of the lane's column (:283-284, narrowed by the cull :277-280 or set by the clip :392-393)
+
+		// ---- pixel loops (lane = pixel) ------------------------------------------------------------------------------------------------
+		// side of a run, :519-533: the unseen pixels of [rbMin, rbMax] get the run's perspective-correct colour
+		auto sidePixels = [&](int rbMin, int rbMax, float boundsX, float boundsY, float uvAx, float uvBx, float uvAy, float uvBy, int elementLength, int elementColorsIndex, uint32_t columnColorsOff) {
+			const TexRun texRun = tex_run(boundsX, boundsY, uvAx, uvBx, uvAy, uvBy);
+			for (int yb = rbMin; yb <= rbMax; yb += CVX_WAVE) {
+				const int n = min(CVX_WAVE, rbMax - yb + 1);
+				const lanemask_t todo = lone_unseen64<HI>(seen, yb) & (n >= CVX_WAVE ? ~0ull : ((1ull << n) - 1ull));
+				if (todo == 0ull) { continue; }
+				CVX_LSTAT(3);
+				CVX_LSTAT_ADD(4, __popcll(todo));
+				frustumDirMaxWorld = CVX_FLOAT_EPSILON; // :522
+				if (__builtin_amdgcn_inverse_ballot_w64(todo)) {
+					const int y = yb + lane;
+					bool certain;
+					int row = tex_row_cheap(y, boundsX, uvAx, uvAy, texRun, certain);
+					if (CVX_RARE(!certain)) { row = tex_row_exact(y, boundsX, boundsY, uvAx, uvBx, uvAy, uvBy); }
+					const int colorIdx = m_clampi(row, 0, elementLength - 1) + elementColorsIndex;
+					const uint32_t c = ld_color(arena, columnColorsOff + ((uint32_t)colorIdx << L.colorShift));
+					st_pixel(tileOut, laneByteOff, y, c);
+				}
+			}
+			lone_mark<HI>(seen, rbMin, rbMax);
+		};
+		// top / bottom of a run, :595-603
+		auto facePixels = [&](int rbMin, int rbMax, uint32_t color) {
+			for (int yb = rbMin; yb <= rbMax; yb += CVX_WAVE) {
+				const int n = min(CVX_WAVE, rbMax - yb + 1);
+				const lanemask_t todo = lone_unseen64<HI>(seen, yb) & (n >= CVX_WAVE ? ~0ull : ((1ull << n) - 1ull));
+				if (todo == 0ull) { continue; }
+				CVX_LSTAT(5);
+				CVX_LSTAT_ADD(6, __popcll(todo));
+				frustumDirMaxWorld = CVX_FLOAT_EPSILON; // :598
+				if (__builtin_amdgcn_inverse_ballot_w64(todo)) { st_pixel(tileOut, laneByteOff, yb + lane, color); }
+			}
+			lone_mark<HI>(seen, rbMin, rbMax);
+		};
+		// one solid run of the column being processed (every operand wave-uniform): :461-475 were tested by the caller; side :484-542, face :544-610
+		auto drawRun = [&](const RunProj &R, float elementBoundsMin, float elementBoundsMax, int elementLength, int elementColorsIndex, uint32_t columnColorsOff, uint32_t secondaryColor,
+		                   float worldBoundsMin, float worldBoundsMax) {
+			if (R.sideVisible) {
+				int rbMin = R.rbMinS, rbMax = R.rbMaxS;
+				if (rbMax >= nextFreePixelMin && rbMin <= nextFreePixelMax) { // :505
+					CVX_LSTAT(7);
+					CVX_LMARK("sidereduce_begin");
+					lone_reduce_pixel_horizon<HI>(seen, omin, omax, rbMin, rbMax, nextFreePixelMin, nextFreePixelMax, frustumBoundsMin, frustumBoundsMax);
+					CVX_LMARK("sidereduce_end");
+					if (rbMin <= rbMax) { sidePixels(rbMin, rbMax, R.boundsX, R.boundsY, R.uvAx, R.uvBx, R.uvAy, R.uvBy, elementLength, elementColorsIndex, columnColorsOff); }
+					if (nextFreePixelMin > nextFreePixelMax) { alive = false; return; } // :535-539
+					CVX_LMARK("sidepixels_end");
+				}
+			}
+			const bool faceWanted = (R.faceTop && !(elementBoundsMax > worldBoundsMax)) || (R.faceBottom && !(elementBoundsMin < worldBoundsMin)); // :549-565
+			if (faceWanted && R.faceNear) {
+				int rbMin = R.rbMinF, rbMax = R.rbMaxF;
+				if (rbMax >= nextFreePixelMin && rbMin <= nextFreePixelMax) { // :581
+					CVX_LSTAT(8);
+					CVX_LMARK("facereduce_begin");
+					lone_reduce_pixel_horizon<HI>(seen, omin, omax, rbMin, rbMax, nextFreePixelMin, nextFreePixelMax, frustumBoundsMin, frustumBoundsMax);
+					CVX_LMARK("facereduce_end");
+					if (rbMin <= rbMax) { facePixels(rbMin, rbMax, secondaryColor); }
+					if (nextFreePixelMin > nextFreePixelMax) { alive = false; return; } // :604-608
+					CVX_LMARK("facepixels_end");
+				}
+			}
+		};
+
+		// ---- element loop (:424-611) of column j, run by run in the reference's walk order, with the ray's current state
+		auto processColumn = [&](int j) {
+			CVX_LSTAT(9);
+			CVX_LMARK("process_begin");
+			const float worldBoundsMin = rlf(wbMin, j), worldBoundsMax = rlf(wbMax, j);
+			const uint32_t fl = rlu(flags, j);
+			const uint32_t columnColorsOff = rlu(colorsOff, j);
+			if (CVX_RARE((fl & CVX_LF_LISTED) != 0u)) {
+				CVX_LSTAT(10);
+				// a column of the run list (cvx_device.h: a few per thousand of a built world, every column of a foreign blob): its runs are fetched and
+				// projected when their turn comes, with wave-uniform operands
+				const uint32_t columnRunsOff = L.runsOff + rlu(rec.z, j) * 8u;
+				const int solidCount = (int)rlu(rec.w, j);
+				const f3 qMinLast = f3{ rlf(camSpaceMinLast.x, j), rlf(camSpaceMinLast.y, j), rlf(camSpaceMinLast.z, j) };
+				const f3 qMaxLast = f3{ rlf(camSpaceMaxLast.x, j), rlf(camSpaceMaxLast.y, j), rlf(camSpaceMaxLast.z, j) };
+				const f3 qMinNext = f3{ rlf(camSpaceMinNext.x, j), rlf(camSpaceMinNext.y, j), rlf(camSpaceMinNext.z, j) };
+				const f3 qMaxNext = f3{ rlf(camSpaceMaxNext.x, j), rlf(camSpaceMaxNext.y, j), rlf(camSpaceMaxNext.z, j) };
+				for (int k = 0; k < solidCount && alive; k++) {
+					const uint2 run = ld2(arena, columnRunsOff + (uint32_t)(DIR > 0 ? k : solidCount - 1 - k) * 8u);
+					const float elementBoundsMin = (float)(run.x & 0xFFFFu), elementBoundsMax = (float)(run.x >> 16) + 1.0f;
+					if (elementBoundsMin > worldBoundsMax || elementBoundsMax < worldBoundsMin) { continue; } // :461-475
+					const int elementLength = (int)(((run.x >> 16) + 1u - (run.x & 0xFFFFu)) >> lod);
+					const int elementColorsIndex = (int)(run.y & 0xFFFFu);
+					RunProj R = project_run(qMinLast, qMaxLast, qMinNext, qMaxNext, elementBoundsMin, elementBoundsMax, elementLength, cameraPosYNormalized, invWorldMaxY);
+					R.rbMinS = uni(R.rbMinS); R.rbMaxS = uni(R.rbMaxS); R.rbMinF = uni(R.rbMinF); R.rbMaxF = uni(R.rbMaxF); // (f2i is inline asm: see uni())
+					const uint32_t secondaryColor = ld_color(arena, columnColorsOff + ((uint32_t)(R.faceTop ? elementColorsIndex : elementColorsIndex + elementLength - 1) << L.colorShift));
+					drawRun(R, elementBoundsMin, elementBoundsMax, elementLength, elementColorsIndex, columnColorsOff, secondaryColor, worldBoundsMin, worldBoundsMax);
+				}
+				return;
+			}
+#pragma unroll
+			for (int rr = 0; rr < 3; rr++) {
+				const int r = DIR > 0 ? rr : 2 - rr; // the walk starts at the top (ITERATION_DIRECTION +1) or at the bottom (-1), :428-437
+				const uint32_t f = fl >> (r * 8);
+				if (alive && (f & CVX_LF_EXISTS) != 0u) {
+					const float elementBoundsMin = (float)rli(runB[r], j), elementBoundsMax = (float)rli(runT[r], j);
+					if (!(elementBoundsMin > worldBoundsMax) && !(elementBoundsMax < worldBoundsMin)) { // :461-475
+						CVX_LSTAT(15);
+						RunProj R;
+						CVX_LMARK("runfetch_begin");
+						R.sideVisible = (f & CVX_LF_SIDE) != 0u;
+						R.faceNear = (f & CVX_LF_FACENEAR) != 0u;
+						R.faceTop = (f & CVX_LF_FACETOP) != 0u;
+						R.faceBottom = (f & CVX_LF_FACEBOTTOM) != 0u;
+						R.rbMinS = rli(P[r].rbMinS, j);
+						R.rbMaxS = rli(P[r].rbMaxS, j);
+						R.rbMinF = rli(P[r].rbMinF, j);
+						R.rbMaxF = rli(P[r].rbMaxF, j);
+						R.boundsX = rlf(P[r].boundsX, j);
+						R.boundsY = rlf(P[r].boundsY, j);
+						R.uvAx = rlf(P[r].uvAx, j);
+						R.uvBx = rlf(P[r].uvBx, j);
+						R.uvAy = rlf(P[r].uvAy, j);
+						R.uvBy = rlf(P[r].uvBy, j);
+						CVX_LMARK("runfetch_end");
+						drawRun(R, elementBoundsMin, elementBoundsMax, rli(runLen[r], j), rli(runCidx[r], j), columnColorsOff, rlu(faceColor[r], j), worldBoundsMin, worldBoundsMax);
+					}
+				}
+			}
+		};
+
+		// ---- frustum clip of column j (:295-422), computed in the column's own lane (the other lanes compute along: their results are not looked at)
+		auto clipColumn = [&](int j) {
+			CVX_LSTAT(11);
+			CVX_LMARK("clip_begin");
+			float clipLastMinLerp, clipLastMaxLerp, clipNextMinLerp, clipNextMaxLerp;
+			const float invFrustumMin = quot_safe(1.0f, recip_safe(frustumBoundsMin)), invFrustumMax = quot_safe(1.0f, recip_safe(frustumBoundsMax));
+			bool straddlesLast, straddlesNext;
+			bool clippedLast, clippedNext;
+			{
+				const auto straddle = [&](f3 pMin, f3 pMax) { return ((int)!(pMin.x > pMin.z * frustumBoundsMax) & (int)(pMin.x < pMin.z * frustumBoundsMin) & (int)(pMax.x > pMax.z * frustumBoundsMax)) != 0; };
+				const bool both = ((int)straddle(camSpaceMinLast, camSpaceMaxLast) & (int)straddle(camSpaceMinNext, camSpaceMaxNext)) != 0;
+				if ((__ballot(both) >> j) & 1ull) { // (the column's own flag: wave-uniform)
+					clipLastMinLerp = clip_min(camSpaceMinLast, camSpaceMaxLast, invFrustumMin);
+					clipLastMaxLerp = clip_max(camSpaceMinLast, camSpaceMaxLast, invFrustumMax);
+					clipNextMinLerp = clip_min(camSpaceMinNext, camSpaceMaxNext, invFrustumMin);
+					clipNextMaxLerp = clip_max(camSpaceMinNext, camSpaceMaxNext, invFrustumMax);
+					clippedLast = clippedNext = false;
+					straddlesLast = straddlesNext = true;
+				} else {
+					CVX_LSTAT(12);
+					clippedLast = clip_world_bounds(camSpaceMinLast, camSpaceMaxLast, frustumBoundsMin, frustumBoundsMax, invFrustumMin, invFrustumMax, clipLastMinLerp, clipLastMaxLerp, straddlesLast);
+					clippedNext = clip_world_bounds(camSpaceMinNext, camSpaceMaxNext, frustumBoundsMin, frustumBoundsMax, invFrustumMin, invFrustumMax, clipNextMinLerp, clipNextMaxLerp, straddlesNext);
+				}
+			}
+			const bool minFromLast = !clippedLast && (clippedNext || clipLastMinLerp < clipNextMinLerp);
+			const bool maxFromLast = !clippedLast && (clippedNext || clipLastMaxLerp > clipNextMaxLerp);
+			float worldBoundsMin = m_lerp(0.0f, worldMaxY, minFromLast ? clipLastMinLerp : clipNextMinLerp);
+			float worldBoundsMax = m_lerp(0.0f, worldMaxY, maxFromLast ? clipLastMaxLerp : clipNextMaxLerp);
+			const float dirMin = (worldBoundsMin - posY) / (minFromLast ? wDistLast : wDistNext);
+			const float dirMax = (worldBoundsMax - posY) / (maxFromLast ? wDistLast : wDistNext);
+			const f3 minClipA = f3_lerp(camSpaceMinLast, camSpaceMaxLast, clipLastMinLerp);
+			const f3 maxClipA = f3_lerp(camSpaceMinLast, camSpaceMaxLast, clipLastMaxLerp);
+			const f3 minClipB = f3_lerp(camSpaceMinNext, camSpaceMaxNext, clipNextMinLerp);
+			const f3 maxClipB = f3_lerp(camSpaceMinNext, camSpaceMaxNext, clipNextMaxLerp);
+			worldBoundsMin = floorf(worldBoundsMin);
+			worldBoundsMax = ceilf(worldBoundsMax);
+			frustumDirMinWorld = rlf(dirMin, j);
+			frustumDirMaxWorld = rlf(dirMax, j);
+			{ // the column's world bounds go into its lane's slot
+				const bool mine = lane == j;
+				wbMin = mine ? worldBoundsMin : wbMin;
+				wbMax = mine ? worldBoundsMax : wbMax;
+			}
+			// "window untouched" (cvx_kernels.h, drawColumn): both ends straddle the window and every clipped point lies on its bound -- then :337-421 change nothing
+			const auto onBound = [](f3 p, float f) { return fabsf(p.x - f * p.z) < 0.4f * fabsf(p.z); };
+			const bool windowUntouched = ((int)straddlesLast & (int)straddlesNext & (int)onBound(minClipA, frustumBoundsMin) & (int)onBound(minClipB, frustumBoundsMin) &
+			                              (int)onBound(maxClipA, frustumBoundsMax) & (int)onBound(maxClipB, frustumBoundsMax)) != 0;
+			CVX_LMARK("clip_end");
+			if (!CVX_USUAL((__ballot(windowUntouched) >> j) & 1ull)) {
+				CVX_LSTAT(13);
+				float minNext = minClipB.x / minClipB.z;
+				float minLast = minClipA.x / minClipA.z;
+				float maxNext = maxClipB.x / maxClipB.z;
+				float maxLast = maxClipA.x / maxClipA.z;
+				if (maxNext < minNext) { float t = maxNext; maxNext = minNext; minNext = t; }
+				if (maxLast < minLast) { float t = maxLast; maxLast = minLast; minLast = t; }
+				const float bothMin = hw_min(minLast, minNext), bothMax = hw_max(maxLast, maxNext);
+				const float camSpaceClippedMin = clippedLast ? minNext : (clippedNext ? minLast : bothMin);
+				const float camSpaceClippedMax = clippedLast ? maxNext : (clippedNext ? maxLast : bothMax);
+				const int writableMinPixel = rli(f2i_floor(camSpaceClippedMin), j);
+				const int writableMaxPixel = rli(f2i(ceilf(camSpaceClippedMax)), j);
+				const bool bothClipped = (__ballot(clippedLast && clippedNext) >> j) & 1ull;
+				if (bothClipped || writableMaxPixel < nextFreePixelMin || writableMinPixel > nextFreePixelMax) { // :297-299, :399-403
+					alive = false;
+					return;
+				}
+				if (writableMinPixel > nextFreePixelMin) { nextFreePixelMin = lone_scan_up<HI>(seen, writableMinPixel, omax); }   // :405-410
+				if (writableMaxPixel < nextFreePixelMax) { nextFreePixelMax = lone_scan_down<HI>(seen, writableMaxPixel, omin); } // :411-416
+				if (nextFreePixelMin > nextFreePixelMax) { alive = false; } // :417-421
+				CVX_LMARK("cliptouched_end");
+			}
+		};
+
+		// ---- one pass over the lanes >= from with the ray's current state: the cull of every column (:261-281) and whether any of its runs can touch
+		// the state (:461-475, :505, :549-565, :581).  `clipped` >= 0: that lane's column was just clipped (it is drawn with the clip's world bounds).
+		lanemask_t hits = 0ull, leftWorldMask = 0ull;
+		auto cullAndFilter = [&](int from, int clipped) {
+			CVX_LSTAT(14);
+			CVX_LMARK("filter_begin");
+			const float columnWorldMin = (float)(rec.y & 0xFFFFu);
+			const float columnWorldMax = (float)(rec.y >> 16);
+			const float newMax = posY + hw_max(frustumDirMaxWorld * wDistNext, frustumDirMaxWorld * wDistLast);
+			const float newMin = posY + hw_min(frustumDirMinWorld * wDistNext, frustumDirMinWorld * wDistLast);
+			const bool own = lane == clipped;
+			const bool leftWorld = ((int)nonEmpty & (int)!own & ((int)(newMin > worldMaxY) | (int)(newMax < 0.0f))) != 0;
+			const bool noOverlap = ((int)!own & ((int)(columnWorldMin > newMax) | (int)(columnWorldMax < newMin))) != 0;
+			const bool draw = ((int)nonEmpty & (int)!leftWorld & (int)!noOverlap) != 0;
+			wbMin = own ? wbMin : newMin;
+			wbMax = own ? wbMax : newMax;
+			bool hit = (flags & CVX_LF_LISTED) != 0u; // (a column of the run list: looked at when its turn comes)
+#pragma unroll
+			for (int r = 0; r < 3; r++) {
+				const uint32_t f = flags >> (r * 8);
+				const float b = (float)runB[r], t = (float)runT[r];
+				const bool in = ((int)((f & CVX_LF_EXISTS) != 0u) & (int)!(b > wbMax) & (int)!(t < wbMin)) != 0;
+				const bool side = ((int)((f & CVX_LF_SIDE) != 0u) & (int)(P[r].rbMaxS >= nextFreePixelMin) & (int)(P[r].rbMinS <= nextFreePixelMax)) != 0;
+				const bool wanted = (((int)((f & CVX_LF_FACETOP) != 0u) & (int)!(t > wbMax)) | ((int)((f & CVX_LF_FACEBOTTOM) != 0u) & (int)!(b < wbMin))) != 0;
+				const bool face = ((int)wanted & (int)((f & CVX_LF_FACENEAR) != 0u) & (int)(P[r].rbMaxF >= nextFreePixelMin) & (int)(P[r].rbMinF <= nextFreePixelMax)) != 0;
+				hit = ((int)hit | ((int)in & ((int)side | (int)face))) != 0;
+			}
+			const lanemask_t range = lanes_from(from);
+			hits = __ballot(draw && hit) & range;
+			leftWorldMask = __ballot(leftWorld) & range;
+			CVX_LMARK("filter_end");
+		};
+
+		// ---- the events of the window, in column order
+		int next = 0;         // first lane not yet looked at
+		bool hitsValid = false;
+		while (alive) {
+			if (frustumDirMaxWorld == CVX_FLOAT_EPSILON) {
+				// no valid frustum directions (:261 false): no cull -- the next non-empty column is drawn (:251-256), clipped first when it lies beyond 2 units (:295)
+				const lanemask_t rem = next < CVX_WAVE ? (nonEmptyMask & lanes_from(next)) : 0ull;
+				if (rem == 0ull) { break; }
+				const int j = __ffsll((long long)rem) - 1;
+				if (rlf(wDistLast, j) > 2.0f) {
+					clipColumn(j);
+					if (!alive) { break; }
+					cullAndFilter(j, j);
+					hitsValid = true;
+					// the clipped column itself goes on to its element loop whatever the clip computed (also a direction that happens to BE the sentinel)
+					if ((hits >> j) & 1ull) {
+						processColumn(j);
+						if (frustumDirMaxWorld == CVX_FLOAT_EPSILON) { hitsValid = false; }
+					}
+					next = j + 1;
+				} else {
+					{ const bool mine = lane == j; wbMin = mine ? 0.0f : wbMin; wbMax = mine ? worldMaxY : wbMax; }
+					processColumn(j);
+					next = j + 1;
+					hitsValid = false;
+				}
+			} else {
+				if (!hitsValid) {
+					if (next >= CVX_WAVE) { break; }
+					cullAndFilter(next, -1);
+					hitsValid = true;
+				}
+				const lanemask_t h = next < CVX_WAVE ? (hits & lanes_from(next)) : 0ull;
+				const lanemask_t l = next < CVX_WAVE ? (leftWorldMask & lanes_from(next)) : 0ull;
+				if ((h | l) == 0ull) { break; }
+				const int fh = h != 0ull ? __ffsll((long long)h) - 1 : CVX_WAVE, fl = l != 0ull ? __ffsll((long long)l) - 1 : CVX_WAVE;
+				if (fl < fh) { alive = false; break; } // :265-269: the frustum left the world
+				processColumn(fh);
+				next = fh + 1;
+				if (frustumDirMaxWorld == CVX_FLOAT_EPSILON) { hitsValid = false; } // a pixel was written: the directions are gone (:522,598)
+			}
+		}
+		if (!alive || endCode == 1) { break; }
+		if (endCode == 2) { // NextLOD (:237-243) for the column the ray stands on
+			ray.px = pos >> 16;
+			ray.pz = pos & 0xFFFF;
+			ray.sx = posStepX >> 16;
+			ray.sz = posStepZ;
+			dda_next_lod(ray, voxelScale, dirXNonNegative, dirZNonNegative);
+			lod++;
+			voxelScale *= 2;
+			L = world->level[lod];
+			{ const float next_ = F.lod[min(lod, 5)]; lodMax = lod < 5 ? next_ : __builtin_inff(); }
+			pos = ray.px * 65536 + ray.pz;
+			posStepX = ray.sx * 65536;
+			posStepZ = ray.sz;
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------
+// lone kernel: grid = rays (one DevTile with laneCount 1 each, cvx_gpu.hip DrawBatch), block = 64 (one wave), no LDS.
+// HI: windows of more than 2048 pixels ([origMin, origMax] spans more than 64 mask words: 4K) carry a second mask register.
+// ---------------------------------------------------------------------------
+template <bool HI>
+#ifndef CVX_LONE_WAVES_PER_SIMD
+#define CVX_LONE_WAVES_PER_SIMD 2
+#endif
+__global__ __launch_bounds__(CVX_WAVE, CVX_LONE_WAVES_PER_SIMD) void lone_kernel(const DevFrame *__restrict__ frames, const DevTile *__restrict__ tiles, const DevWorld *__restrict__ world)
+{
+	const DevTile tile = tiles[blockIdx.x];
+	const DevFrame &F = frames[tile.frame];
+	const DevSegment &S = F.seg[tile.seg];
+	const int firstLane = tile.lanes & 0xFF;
+	const int planeRayIndex = tile.tileInSeg * CVX_WAVE + firstLane; // RaySetupJob (:19-39)
+	if (planeRayIndex >= S.rayCount) { return; }
+	const int omin = S.omin, omax = S.omax;
+	LoneSeen seen;
+	seen.w0 = seen.w1 = 0u; // stackalloc is zero-initialised, :208
+	seen.wordBase = omin >> 5;
+	seen.lane = (int)threadIdx.x;
+	const gptr_tile tileOut = (gptr_tile)tile.out;
+	const uint32_t laneByteOff = (uint32_t)firstLane * 4u;
+#ifdef CVX_LONE_STATS
+	unsigned int stat_[32];
+	for (int i = 0; i < 32; i++) { stat_[i] = 0u; }
+#else
+	unsigned int *stat_ = nullptr;
+#endif
+	if (F.inverse) { // RenderJob.Execute :174-178
+		lone_trace_ray<-1, HI>(F, S, world, planeRayIndex, tileOut, laneByteOff, seen, stat_);
+	} else {
+		lone_trace_ray<1, HI>(F, S, world, planeRayIndex, tileOut, laneByteOff, seen, stat_);
+	}
+#ifdef CVX_LONE_STATS
+	stat_[16]++;
+	if (threadIdx.x == 0) {
+		for (int i = 0; i < 32; i++) { atomicAdd(&g_loneStats[i], (unsigned long long)stat_[i]); }
+	}
+#endif
+	// WriteSkybox / WriteSkyboxFull (:699-716): every pixel of [omin, omax] not marked seen gets the skybox colour (lane = mask word)
+	{
+		const int w = seen.wordBase + seen.lane;
+		uint32_t todo = ~seen.w0 & range_mask_any(w, omin, omax);
+		while (todo != 0u) {
+			const int y = (w << 5) + (__ffs((int)todo) - 1);
+			todo &= todo - 1u;
+			st_pixel_stream(tileOut, laneByteOff, y, CVX_SKYBOX_ARGB);
+		}
+	}
+	if (HI) {
+		const int w = seen.wordBase + 64 + seen.lane;
+		uint32_t todo = ~seen.w1 & range_mask_any(w, omin, omax);
+		while (todo != 0u) {
+			const int y = (w << 5) + (__ffs((int)todo) - 1);
+			todo &= todo - 1u;
+			st_pixel_stream(tileOut, laneByteOff, y, CVX_SKYBOX_ARGB);
+		}
+	}
+}
+
+} // namespace cvxk

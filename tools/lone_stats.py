@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Event counts of the latency kernel (cvx_lone.h) per frame: python3 tools/lone_stats.py [poses] [width height] [world] [lod-error]
+needs the counting variant: make -C cpuvox_amd/csrc variant NAME=lonestats DEFS=-DCVX_LONE_STATS"""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["CVX_GPU_LIB"] = os.path.join(ROOT, "cpuvox_amd", "libcpuvox_gpu_lonestats.so")
+
+import torch  # noqa: F401,E402
+
+from cpuvox_amd import gpu, host  # noqa: E402
+
+poses = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+W, H = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1920, 1080)
+world = sys.argv[4] if len(sys.argv) > 4 else "proc2048"
+lod_error = float(sys.argv[5]) if len(sys.argv) > 5 else 1.0
+dim = int(world[4:])
+ws = host.WorldSet.procedural(dim, dim, dim, 0x5EED2048)
+lods, far = host.setup_lods(host.camera_pose((0, 0, 0), (0, 0, 0), W, H), ws.max_dimension, W, H, lod_error)
+ctx = gpu.Context(0)
+ctx.upload_world(ws)
+ctx.set_resolution(W, H)
+lib = ctypes.CDLL(os.environ["CVX_GPU_LIB"])
+out = (ctypes.c_uint64 * 32)()
+lib.cvx_debug_lone_stats(out, 1)
+for g in range(poses):
+    pos, eul = host.sample_benchmark_path(((g * 37) % 1000) / 1000 * host.BENCHMARK_PATH_LENGTH, ws.dims)
+    ctx.draw_segments(host.setup_frame(host.camera_pose(pos, eul, W, H), lods, far, W, H, ws.dims[1]), 0)
+lib.cvx_debug_lone_stats(out, 0)
+names = ["windows", "columns", "run projections (per window and run index)", "side trips", "side pixels", "face trips", "face pixels", "side overlaps (:505)", "face overlaps (:581)",
+         "processColumn", "... listed", "clipColumn", "... general form", "... window touched", "cullAndFilter", "runs inside the world bounds", "rays"]
+print(f"per frame ({poses} frames {W}x{H} {world}):")
+for i, n in enumerate(names):
+    print(f"  {n:50s} {out[i] / poses:12.1f}")
+ctx.close()
