@@ -102,7 +102,7 @@ struct cvx_context {
 	bool maxWaveMaskWordsAuto = true;     // ... chosen per launch by DrawBatch's cost model unless CVX_MAX_WAVE_MASK_WORDS pins it
 
 	int launchLone = 0;              // the current launch goes to lone_kernel (cvx_lone.h): 1 = one mask register, 2 = two (windows of more than 2048 pixels)
-	int loneMode = 0;                // (work in progress: off unless CVX_LONE=1 in the experiment build) 1: lone_kernel for launches of at most loneWaveBudget rays; experiment build: CVX_LONE=0 never, CVX_LONE=1 (-> 2) always
+	int loneMode = 1;                // 1: lone_kernel for launches of at most loneWaveBudget rays; experiment build: CVX_LONE=0 never, CVX_LONE=1 (-> 2) always
 	int loneWaveBudget = 16384;      // rays (= waves) up to which a launch goes to lone_kernel
 
 	int shardIndex = 0, shardCount = 1;

@@ -279,7 +279,7 @@ __device__ __forceinline__ RunProj project_run(f3 camSpaceMinLast, f3 camSpaceMa
 // ---------------------------------------------------------------------------
 template <int DIR, bool HI>
 __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegment &S, const DevWorld *__restrict__ world, int planeRayIndex, gptr_tile tileOut, uint32_t laneByteOff,
-                                               LoneSeen &seen, unsigned int *stat_)
+                                               LoneSeen &seen, uint32_t *merged /* 64 words of LDS */, unsigned int *stat_)
 {
 	(void)stat_;
 	const int lane = seen.lane;
@@ -378,31 +378,64 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 	bool alive = true; // false: the ray is finished (every exit of the reference is WriteSkybox, which the caller does)
 	while (alive) {
 		// ================= the window: the ray's next (up to) 64 columns at this level =================
-		// Lane k latches the column the DDA stands on after k steps; the steps are the reference's (Step :135-150), wave-uniform.  The window ends early at
-		// the far clip / the world's edge (:613, :246: the ray ends after it) and at this level's LOD distance (:237-243: NextLOD, then the next window).
-		float wDistLast = 0.0f, wDistNext = 0.0f;
-		int wPos = 0;
-		int count = 0;
-		int endCode = 0; // 0: 64 columns, more at this level; 1: the ray ends after this window; 2: LOD boundary
-		for (int k = 0; k < CVX_WAVE; k++) {
-			const bool mine = lane == k;
+		// SegmentDDAData.Step (:135-150) advances the axis with the smaller tMax by its tDelta: the crossing distances of the x planes, X[n] = tMax.x + n additions
+		// of tDelta.x, and of the z planes, Z[m], are two chains that do not depend on each other; the DDA merges them (ties: z first, `tMax.x < tMax.y` :138).
+		// So: lane n computes X[n] and Z[n] -- the reference's own additions in the reference's order, lane n simply stops after n of them --, a binary
+		// search over the other chain gives every crossing its rank in the merged order, and the crossing of rank k is the one column k is LEFT through:
+		// IntersectionDistances of column k = (crossing k - 1, crossing k) (:139-147).  ~7 instructions per column instead of the ~45 of stepping one by one.
+		float wDistLast, wDistNext;
+		int wPos;
+		int count;
+		int endCode = 0; // 0: 64 columns, more at this level; 1: the ray ends after this window (far clip :613 / left the world :246); 2: LOD boundary (:237-243)
+		{
 			CVX_LMARK("dda_begin");
-			wDistLast = mine ? ray.distLast : wDistLast;
-			wDistNext = mine ? ray.distNext : wDistNext;
-			wPos = mine ? pos : wPos;
-			count = k + 1;
-			{ // Step
-				const bool stepX = ray.tMaxX < ray.tMaxZ;
-				const float crossed = ray.distNext; // (the smaller tMax: see dda_step_cursor)
-				const float nextX = ray.tMaxX + ray.tDeltaX, nextZ = ray.tMaxZ + ray.tDeltaZ;
-				ray.tMaxX = stepX ? nextX : ray.tMaxX;
-				ray.tMaxZ = stepX ? ray.tMaxZ : nextZ;
-				pos += stepX ? posStepX : posStepZ;
-				ray.distLast = crossed;
-				ray.distNext = ray.tMaxX < ray.tMaxZ ? ray.tMaxX : ray.tMaxZ; // cmin(tMax) (:147): finite positive sums; the same compare picks the next step's axis
+			float X = ray.tMaxX, Z = ray.tMaxZ;
+#pragma unroll
+			for (int k = 1; k < CVX_WAVE; k++) {
+				const bool further = lane >= k;
+				const float nx_ = X + ray.tDeltaX, nz_ = Z + ray.tDeltaZ;
+				X = further ? nx_ : X;
+				Z = further ? nz_ : Z;
 			}
-			if (ray.distLast >= farClip || (pos & outsideBits) != 0) { endCode = 1; break; }
-			if (ray.distLast >= lodMax) { endCode = 2; break; }
+			// rank of X[lane] = lane + #{m : Z[m] <= X[lane]}; rank of Z[lane] = lane + #{n : X[n] < Z[lane]}
+			int belowX = 0, belowZ = 0;
+#pragma unroll
+			for (int step = CVX_WAVE; step >= 1; step >>= 1) {
+				const int ix = belowX + step - 1, iz = belowZ + step - 1;
+				const float zv = __int_as_float(__builtin_amdgcn_ds_bpermute((ix & 63) << 2, __float_as_int(Z)));
+				const float xv = __int_as_float(__builtin_amdgcn_ds_bpermute((iz & 63) << 2, __float_as_int(X)));
+				belowX += (ix < CVX_WAVE && zv <= X) ? step : 0;
+				belowZ += (iz < CVX_WAVE && xv < Z) ? step : 0;
+			}
+			const int rankX = lane + belowX, rankZ = lane + belowZ;
+			// the crossings in merged order: slot k of the wave's 64 words of LDS receives crossing k (an x crossing with its sign bit set: distances are >= 0)
+			if (rankX < CVX_WAVE) { merged[rankX] = __float_as_uint(X) | 0x80000000u; }
+			if (rankZ < CVX_WAVE) { merged[rankZ] = __float_as_uint(Z); }
+			const uint32_t crossing = merged[lane];
+			const bool alongX = (int)crossing < 0;
+			const float C = __uint_as_float(crossing & 0x7FFFFFFFu);
+			const lanemask_t xBits = __ballot(alongX);
+			const int nxBefore = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(xBits >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)xBits, 0u)); // x steps among the crossings before this lane's
+			wPos = pos + nxBefore * posStepX + (lane - nxBefore) * posStepZ;
+			const int posAfter = wPos + (alongX ? posStepX : posStepZ);
+			wDistNext = C;
+			wDistLast = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ray.distLast), __float_as_int(C), 0x138, 0xF, 0xF, false)); // wave_shr:1, lane 0 keeps the entry distance
+			// the window ends with the first column whose exit crossing reaches the far clip / this level's LOD distance, or leads out of the world
+			const float stopDistance = m_min(farClip, lodMax);
+			const lanemask_t stops = __ballot(C >= stopDistance || (posAfter & outsideBits) != 0);
+			count = stops != 0ull ? __ffsll((long long)stops) : CVX_WAVE;
+			const int last = count - 1;
+			const float exitDistance = rlf(C, last);
+			const int exitPos = rli(posAfter, last);
+			if (stops != 0ull) { endCode = (exitDistance >= farClip || (exitPos & outsideBits) != 0) ? 1 : 2; }
+			// the DDA after `count` steps
+			const int stepsX = __popcll(count < CVX_WAVE ? (xBits & ~lanes_from(count)) : xBits), stepsZ = count - stepsX;
+			const float lastX = rlf(X, min(stepsX, CVX_WAVE - 1)), lastZ = rlf(Z, min(stepsZ, CVX_WAVE - 1));
+			ray.tMaxX = stepsX < CVX_WAVE ? lastX : lastX + ray.tDeltaX;
+			ray.tMaxZ = stepsZ < CVX_WAVE ? lastZ : lastZ + ray.tDeltaZ;
+			ray.distLast = exitDistance;
+			ray.distNext = ray.tMaxX < ray.tMaxZ ? ray.tMaxX : ray.tMaxZ; // cmin(tMax) (:147): finite sums of positive terms
+			pos = exitPos;
 			CVX_LMARK("dda_end");
 		}
 		guardSteps -= count;
@@ -446,12 +479,14 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 		RunProj P[3];
 		uint32_t faceColor[3];
 		uint32_t flags = listed ? CVX_LF_LISTED : 0u;
+		bool anyRun[3];
 #pragma unroll
 		for (int r = 0; r < 3; r++) {
 			const bool exists = r < code;
 			faceColor[r] = 0u;
 			P[r] = RunProj{};
-			if (r == 0 || __ballot(exists) != 0ull) { CVX_LSTAT(2); // (wave-uniform: a window without a second / third run anywhere skips their projections)
+			anyRun[r] = r == 0 || __ballot(exists) != 0ull;
+			if (anyRun[r]) { CVX_LSTAT(2); // (wave-uniform: a window without a second / third run anywhere skips their projections)
 				P[r] = project_run(camSpaceMinLast, camSpaceMaxLast, camSpaceMinNext, camSpaceMaxNext, (float)runB[r], (float)runT[r], runLen[r], cameraPosYNormalized, invWorldMaxY);
 				if (exists) {
 					// :553,560: the run's first colour for a top face, its last for a bottom face (read for every run: the address is a colour of this run either way)
@@ -594,68 +629,79 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 		};
 
 		// ---- frustum clip of column j (:295-422), computed in the column's own lane (the other lanes compute along: their results are not looked at)
+		// The clip's eight division chains are the same four computations -- (Last | Next intersection) x (lower | upper window bound) -- on different operands:
+		// they run in FOUR LANES at once (lanes = operations; every quad of the wave computes the same four, so no lane has to be switched off).  Lane role
+		// c = lane & 3: bit 0 = the upper bound ("max": clip_max against frustumBoundsMax in the ordinary case), bit 1 = the Next intersection.  Partners are
+		// exchanged inside the quad (DPP quad_perm).  Every value is computed by the reference's operations on the reference's operands, as clip_min / clip_max /
+		// clip_world_bounds (cvx_kernels.h) do -- one lane each instead of one after the other.
+		const bool roleMax = (lane & 1) != 0, roleNext = (lane & 2) != 0;
+		auto quadSwapNext = [](float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true)); }; // quad_perm:[2,3,0,1]: Last <-> Next
+		auto quadSwapMax = [](float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true)); };  // quad_perm:[1,0,3,2]: min <-> max
 		auto clipColumn = [&](int j) {
 			CVX_LSTAT(11);
 			CVX_LMARK("clip_begin");
-			float clipLastMinLerp, clipLastMaxLerp, clipNextMinLerp, clipNextMaxLerp;
-			const float invFrustumMin = quot_safe(1.0f, recip_safe(frustumBoundsMin)), invFrustumMax = quot_safe(1.0f, recip_safe(frustumBoundsMax));
-			bool straddlesLast, straddlesNext;
-			bool clippedLast, clippedNext;
-			{
-				const auto straddle = [&](f3 pMin, f3 pMax) { return ((int)!(pMin.x > pMin.z * frustumBoundsMax) & (int)(pMin.x < pMin.z * frustumBoundsMin) & (int)(pMax.x > pMax.z * frustumBoundsMax)) != 0; };
-				const bool both = ((int)straddle(camSpaceMinLast, camSpaceMaxLast) & (int)straddle(camSpaceMinNext, camSpaceMaxNext)) != 0;
-				if ((__ballot(both) >> j) & 1ull) { // (the column's own flag: wave-uniform)
-					clipLastMinLerp = clip_min(camSpaceMinLast, camSpaceMaxLast, invFrustumMin);
-					clipLastMaxLerp = clip_max(camSpaceMinLast, camSpaceMaxLast, invFrustumMax);
-					clipNextMinLerp = clip_min(camSpaceMinNext, camSpaceMaxNext, invFrustumMin);
-					clipNextMaxLerp = clip_max(camSpaceMinNext, camSpaceMaxNext, invFrustumMax);
-					clippedLast = clippedNext = false;
-					straddlesLast = straddlesNext = true;
-				} else {
-					CVX_LSTAT(12);
-					clippedLast = clip_world_bounds(camSpaceMinLast, camSpaceMaxLast, frustumBoundsMin, frustumBoundsMax, invFrustumMin, invFrustumMax, clipLastMinLerp, clipLastMaxLerp, straddlesLast);
-					clippedNext = clip_world_bounds(camSpaceMinNext, camSpaceMaxNext, frustumBoundsMin, frustumBoundsMax, invFrustumMin, invFrustumMax, clipNextMinLerp, clipNextMaxLerp, straddlesNext);
-				}
-			}
-			const bool minFromLast = !clippedLast && (clippedNext || clipLastMinLerp < clipNextMinLerp);
-			const bool maxFromLast = !clippedLast && (clippedNext || clipLastMaxLerp > clipNextMaxLerp);
-			float worldBoundsMin = m_lerp(0.0f, worldMaxY, minFromLast ? clipLastMinLerp : clipNextMinLerp);
-			float worldBoundsMax = m_lerp(0.0f, worldMaxY, maxFromLast ? clipLastMaxLerp : clipNextMaxLerp);
-			const float dirMin = (worldBoundsMin - posY) / (minFromLast ? wDistLast : wDistNext);
-			const float dirMax = (worldBoundsMax - posY) / (maxFromLast ? wDistLast : wDistNext);
-			const f3 minClipA = f3_lerp(camSpaceMinLast, camSpaceMaxLast, clipLastMinLerp);
-			const f3 maxClipA = f3_lerp(camSpaceMinLast, camSpaceMaxLast, clipLastMaxLerp);
-			const f3 minClipB = f3_lerp(camSpaceMinNext, camSpaceMaxNext, clipNextMinLerp);
-			const f3 maxClipB = f3_lerp(camSpaceMinNext, camSpaceMaxNext, clipNextMaxLerp);
-			worldBoundsMin = floorf(worldBoundsMin);
-			worldBoundsMax = ceilf(worldBoundsMax);
-			frustumDirMinWorld = rlf(dirMin, j);
-			frustumDirMaxWorld = rlf(dirMax, j);
+			const float dL = rlf(wDistLast, j), dN = rlf(wDistNext, j);
+			const float dist = roleNext ? dN : dL;
+			// :289-293 for this lane's intersection (x and z: the clip never looks at y)
+			const float px_ = planeDir.x * dist, pz_ = planeDir.z * dist;
+			const float pMinX = planeStartBottom.x + px_, pMinZ = planeStartBottom.z + pz_, pMaxX = planeStartTop.x + px_, pMaxZ = planeStartTop.z + pz_;
+			// GetWorldBoundsClippingCamSpace, CameraData.cs:51-99 (the flattened form of clip_world_bounds)
+			const bool a1 = pMinX > pMinZ * frustumBoundsMax;
+			const bool a2 = pMaxX > pMaxZ * frustumBoundsMax;
+			const bool b1 = pMinX < pMinZ * frustumBoundsMin;
+			const bool b2 = pMaxX < pMaxZ * frustumBoundsMin;
+			const bool n1 = !a1, n2 = !a2;
+			const bool straddles = CVX_AND(CVX_AND(n1, b1), a2);
+			const bool need = roleMax ? CVX_OR(CVX_AND(a1, b2), CVX_AND(n1, CVX_OR(a2, b2))) : CVX_OR(a1, b1);
+			const bool againstMax = roleMax ? CVX_AND(n1, a2) : a1; // which window bound this lane's clip is made against
+			const bool clipped = CVX_OR(CVX_AND(a1, a2), CVX_AND(CVX_AND(n1, n2), CVX_AND(b1, b2)));
+			const float finv = quot_safe(1.0f, recip_safe(againstMax ? frustumBoundsMax : frustumBoundsMin)); // CameraData.cs:103,111
+			const float c0 = 1.0f * pMaxZ - finv * pMaxX;
+			const float c1 = 1.0f * pMinZ - finv * pMinX;
+			const float num = roleMax ? c1 : c0, oth = roleMax ? c0 : c1;
+			const float q = num / (num - oth);
+			const float clipT = roleMax ? q : 1.0f - q; // clip_max: c1 / (c1 - c0); clip_min: 1 - c0 / (c0 - c1)
+			const float lerpT = need ? clipT : (roleMax ? 1.0f : 0.0f);
+			const lanemask_t clippedBits = __ballot(clipped), straddleBits = __ballot(straddles);
+			const bool clippedLast = (clippedBits & 1ull) != 0ull, clippedNext = (clippedBits & 4ull) != 0ull;
+			if (!(straddleBits & 1ull) || !(straddleBits & 4ull)) { CVX_LSTAT(12); }
+			// :300-390: each bound from the Last or the Next intersection
+			const float otherT = quadSwapNext(lerpT);
+			const float lastT = roleNext ? otherT : lerpT, nextT = roleNext ? lerpT : otherT;
+			const bool closer = roleMax ? lastT > nextT : lastT < nextT;
+			const bool fromLast = !clippedLast && (clippedNext || closer);
+			float worldBounds = m_lerp(0.0f, worldMaxY, fromLast ? lastT : nextT);
+			const float dir = (worldBounds - posY) / (fromLast ? dL : dN);
+			worldBounds = roleMax ? ceilf(worldBounds) : floorf(worldBounds);
+			frustumDirMinWorld = rlf(dir, 0);
+			frustumDirMaxWorld = rlf(dir, 1);
+			const float clipWbMin = rlf(worldBounds, 0), clipWbMax = rlf(worldBounds, 1);
 			{ // the column's world bounds go into its lane's slot
 				const bool mine = lane == j;
-				wbMin = mine ? worldBoundsMin : wbMin;
-				wbMax = mine ? worldBoundsMax : wbMax;
+				wbMin = mine ? clipWbMin : wbMin;
+				wbMax = mine ? clipWbMax : wbMax;
 			}
-			// "window untouched" (cvx_kernels.h, drawColumn): both ends straddle the window and every clipped point lies on its bound -- then :337-421 change nothing
-			const auto onBound = [](f3 p, float f) { return fabsf(p.x - f * p.z) < 0.4f * fabsf(p.z); };
-			const bool windowUntouched = ((int)straddlesLast & (int)straddlesNext & (int)onBound(minClipA, frustumBoundsMin) & (int)onBound(minClipB, frustumBoundsMin) &
-			                              (int)onBound(maxClipA, frustumBoundsMax) & (int)onBound(maxClipB, frustumBoundsMax)) != 0;
+			// the clipped point of this lane (x, z) and "window untouched" (cvx_kernels.h, drawColumn): both ends straddle the window and every clipped point lies
+			// on its bound -- then :337-421 change nothing
+			const float ptX = pMinX + (pMaxX - pMinX) * lerpT, ptZ = pMinZ + (pMaxZ - pMinZ) * lerpT;
+			const bool onBound = fabsf(ptX - (roleMax ? frustumBoundsMax : frustumBoundsMin) * ptZ) < 0.4f * fabsf(ptZ);
+			const bool windowUntouched = (__ballot(straddles && onBound) & 0xFull) == 0xFull;
 			CVX_LMARK("clip_end");
-			if (!CVX_USUAL((__ballot(windowUntouched) >> j) & 1ull)) {
+			if (!CVX_USUAL(windowUntouched)) {
 				CVX_LSTAT(13);
-				float minNext = minClipB.x / minClipB.z;
-				float minLast = minClipA.x / minClipA.z;
-				float maxNext = maxClipB.x / maxClipB.z;
-				float maxLast = maxClipA.x / maxClipA.z;
-				if (maxNext < minNext) { float t = maxNext; maxNext = minNext; minNext = t; }
-				if (maxLast < minLast) { float t = maxLast; maxLast = minLast; minLast = t; }
-				const float bothMin = hw_min(minLast, minNext), bothMax = hw_max(maxLast, maxNext);
-				const float camSpaceClippedMin = clippedLast ? minNext : (clippedNext ? minLast : bothMin);
-				const float camSpaceClippedMax = clippedLast ? maxNext : (clippedNext ? maxLast : bothMax);
-				const int writableMinPixel = rli(f2i_floor(camSpaceClippedMin), j);
-				const int writableMaxPixel = rli(f2i(ceilf(camSpaceClippedMax)), j);
-				const bool bothClipped = (__ballot(clippedLast && clippedNext) >> j) & 1ull;
-				if (bothClipped || writableMaxPixel < nextFreePixelMin || writableMinPixel > nextFreePixelMax) { // :297-299, :399-403
+				const float mine = ptX / ptZ; // lanes: minLast, maxLast, minNext, maxNext
+				const float partner = quadSwapMax(mine);
+				const bool sw = roleMax ? mine < partner : partner < mine; // :339-346: max < min -> swap
+				const float v = sw ? partner : mine;
+				const float o = quadSwapNext(v);
+				const float lastV = roleNext ? o : v, nextV = roleNext ? v : o;
+				const float bothMin = hw_min(lastV, nextV), bothMax = hw_max(lastV, nextV);
+				const float both = roleMax ? bothMax : bothMin;
+				const float camSpaceClipped = clippedLast ? nextV : (clippedNext ? lastV : both);
+				const int pixelFloor = f2i_floor(camSpaceClipped), pixelCeil = f2i(ceilf(camSpaceClipped));
+				const int writableMinPixel = rli(pixelFloor, 0);
+				const int writableMaxPixel = rli(pixelCeil, 1);
+				if ((clippedLast && clippedNext) || writableMaxPixel < nextFreePixelMin || writableMinPixel > nextFreePixelMax) { // :297-299, :399-403
 					alive = false;
 					return;
 				}
@@ -685,6 +731,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 			bool hit = (flags & CVX_LF_LISTED) != 0u; // (a column of the run list: looked at when its turn comes)
 #pragma unroll
 			for (int r = 0; r < 3; r++) {
+				if (r > 0 && !anyRun[r]) { continue; } // (wave-uniform: no column of the window has such a run)
 				const uint32_t f = flags >> (r * 8);
 				const float b = (float)runB[r], t = (float)runT[r];
 				const bool in = ((int)((f & CVX_LF_EXISTS) != 0u) & (int)!(b > wbMax) & (int)!(t < wbMin)) != 0;
@@ -769,6 +816,7 @@ template <bool HI>
 #endif
 __global__ __launch_bounds__(CVX_WAVE, CVX_LONE_WAVES_PER_SIMD) void lone_kernel(const DevFrame *__restrict__ frames, const DevTile *__restrict__ tiles, const DevWorld *__restrict__ world)
 {
+	__shared__ uint32_t merged[CVX_WAVE]; // the DDA's crossings in merged order (lone_trace_ray)
 	const DevTile tile = tiles[blockIdx.x];
 	const DevFrame &F = frames[tile.frame];
 	const DevSegment &S = F.seg[tile.seg];
@@ -789,9 +837,9 @@ __global__ __launch_bounds__(CVX_WAVE, CVX_LONE_WAVES_PER_SIMD) void lone_kernel
 	unsigned int *stat_ = nullptr;
 #endif
 	if (F.inverse) { // RenderJob.Execute :174-178
-		lone_trace_ray<-1, HI>(F, S, world, planeRayIndex, tileOut, laneByteOff, seen, stat_);
+		lone_trace_ray<-1, HI>(F, S, world, planeRayIndex, tileOut, laneByteOff, seen, merged, stat_);
 	} else {
-		lone_trace_ray<1, HI>(F, S, world, planeRayIndex, tileOut, laneByteOff, seen, stat_);
+		lone_trace_ray<1, HI>(F, S, world, planeRayIndex, tileOut, laneByteOff, seen, merged, stat_);
 	}
 #ifdef CVX_LONE_STATS
 	stat_[16]++;
