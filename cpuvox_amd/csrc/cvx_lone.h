@@ -42,12 +42,19 @@ typedef unsigned long long lanemask_t;
 #define CVX_LMARK(name) ((void)0)
 #endif
 #ifdef CVX_LONE_STATS
-__device__ unsigned long long g_loneStats[32];
+__device__ unsigned long long g_loneStats[48];
 #define CVX_LSTAT(n) (stat_[n]++)
 #define CVX_LSTAT_ADD(n, v) (stat_[n] += (unsigned int)(v))
+// section clock (s_memtime): the cycles since the last switch go to the section that was current; stat_[32 + section]
+#ifdef CVX_LONE_TIMES
+#define CVX_LSEC(n) do { const unsigned int t_ = (unsigned int)__builtin_amdgcn_s_memtime(); stat_[32 + stat_[31]] += t_ - stat_[30]; stat_[30] = t_; stat_[31] = (n); } while (0)
+#else
+#define CVX_LSEC(n) ((void)0)
+#endif
 #else
 #define CVX_LSTAT(n) ((void)0)
 #define CVX_LSTAT_ADD(n, v) ((void)0)
+#define CVX_LSEC(n) ((void)0)
 #endif
 
 __device__ __forceinline__ float rlf(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
@@ -389,6 +396,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 		int endCode = 0; // 0: 64 columns, more at this level; 1: the ray ends after this window (far clip :613 / left the world :246); 2: LOD boundary (:237-243)
 		{
 			CVX_LMARK("dda_begin");
+			CVX_LSEC(1);
 			float X = ray.tMaxX, Z = ray.tMaxZ;
 #pragma unroll
 			for (int k = 1; k < CVX_WAVE; k++) {
@@ -443,6 +451,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 		CVX_LSTAT(0);
 		CVX_LSTAT_ADD(1, count);
 
+		CVX_LSEC(2);
 		CVX_LMARK("winsetup_begin");
 		// ---- the window's records: one load per lane, all in flight together
 		const bool valid = lane < count;
@@ -499,6 +508,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 		}
 
 		CVX_LMARK("winsetup_end");
+		uint32_t todo = 0u;                    // (runTests, below)
 		float wbMin = 0.0f, wbMax = worldMaxY; // worldBoundsMin / Max of the lane's column (:283-284, narrowed by the cull :277-280 or set by the clip :392-393)
 
 		// ---- pixel loops (lane = pixel) ------------------------------------------------------------------------------------------------
@@ -545,11 +555,14 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 				if (rbMax >= nextFreePixelMin && rbMin <= nextFreePixelMax) { // :505
 					CVX_LSTAT(7);
 					CVX_LMARK("sidereduce_begin");
+					CVX_LSEC(7);
 					lone_reduce_pixel_horizon<HI>(seen, omin, omax, rbMin, rbMax, nextFreePixelMin, nextFreePixelMax, frustumBoundsMin, frustumBoundsMax);
 					CVX_LMARK("sidereduce_end");
+					CVX_LSEC(8);
 					if (rbMin <= rbMax) { sidePixels(rbMin, rbMax, R.boundsX, R.boundsY, R.uvAx, R.uvBx, R.uvAy, R.uvBy, elementLength, elementColorsIndex, columnColorsOff); }
 					if (nextFreePixelMin > nextFreePixelMax) { alive = false; return; } // :535-539
 					CVX_LMARK("sidepixels_end");
+					CVX_LSEC(6);
 				}
 			}
 			const bool faceWanted = (R.faceTop && !(elementBoundsMax > worldBoundsMax)) || (R.faceBottom && !(elementBoundsMin < worldBoundsMin)); // :549-565
@@ -558,11 +571,14 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 				if (rbMax >= nextFreePixelMin && rbMin <= nextFreePixelMax) { // :581
 					CVX_LSTAT(8);
 					CVX_LMARK("facereduce_begin");
+					CVX_LSEC(9);
 					lone_reduce_pixel_horizon<HI>(seen, omin, omax, rbMin, rbMax, nextFreePixelMin, nextFreePixelMax, frustumBoundsMin, frustumBoundsMax);
 					CVX_LMARK("facereduce_end");
+					CVX_LSEC(10);
 					if (rbMin <= rbMax) { facePixels(rbMin, rbMax, secondaryColor); }
 					if (nextFreePixelMin > nextFreePixelMax) { alive = false; return; } // :604-608
 					CVX_LMARK("facepixels_end");
+					CVX_LSEC(6);
 				}
 			}
 		};
@@ -571,11 +587,12 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 		auto processColumn = [&](int j) {
 			CVX_LSTAT(9);
 			CVX_LMARK("process_begin");
-			const float worldBoundsMin = rlf(wbMin, j), worldBoundsMax = rlf(wbMax, j);
-			const uint32_t fl = rlu(flags, j);
-			const uint32_t columnColorsOff = rlu(colorsOff, j);
-			if (CVX_RARE((fl & CVX_LF_LISTED) != 0u)) {
+			CVX_LSEC(6);
+			const uint32_t bits = rlu(todo, j);
+			if (CVX_RARE((bits & 0x80000000u) != 0u)) {
 				CVX_LSTAT(10);
+				const float worldBoundsMin = rlf(wbMin, j), worldBoundsMax = rlf(wbMax, j);
+				const uint32_t columnColorsOff = rlu(colorsOff, j);
 				// a column of the run list (cvx_device.h: a few per thousand of a built world, every column of a foreign blob): its runs are fetched and
 				// projected when their turn comes, with wave-uniform operands
 				const uint32_t columnRunsOff = L.runsOff + rlu(rec.z, j) * 8u;
@@ -597,32 +614,43 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 				}
 				return;
 			}
+			// the runs the last pass over the window found able to touch the state (runTests: inside the column's world bounds :461-475, a visible side whose
+			// pixels overlapped [nextFreePixelMin, Max] :505, a wanted visible face that did :549-565,581), in the reference's walk order; the window can only
+			// have shrunk since, so each is tested again against the current one
 #pragma unroll
 			for (int rr = 0; rr < 3; rr++) {
 				const int r = DIR > 0 ? rr : 2 - rr; // the walk starts at the top (ITERATION_DIRECTION +1) or at the bottom (-1), :428-437
-				const uint32_t f = fl >> (r * 8);
-				if (alive && (f & CVX_LF_EXISTS) != 0u) {
-					const float elementBoundsMin = (float)rli(runB[r], j), elementBoundsMax = (float)rli(runT[r], j);
-					if (!(elementBoundsMin > worldBoundsMax) && !(elementBoundsMax < worldBoundsMin)) { // :461-475
-						CVX_LSTAT(15);
-						RunProj R;
-						CVX_LMARK("runfetch_begin");
-						R.sideVisible = (f & CVX_LF_SIDE) != 0u;
-						R.faceNear = (f & CVX_LF_FACENEAR) != 0u;
-						R.faceTop = (f & CVX_LF_FACETOP) != 0u;
-						R.faceBottom = (f & CVX_LF_FACEBOTTOM) != 0u;
-						R.rbMinS = rli(P[r].rbMinS, j);
-						R.rbMaxS = rli(P[r].rbMaxS, j);
-						R.rbMinF = rli(P[r].rbMinF, j);
-						R.rbMaxF = rli(P[r].rbMaxF, j);
-						R.boundsX = rlf(P[r].boundsX, j);
-						R.boundsY = rlf(P[r].boundsY, j);
-						R.uvAx = rlf(P[r].uvAx, j);
-						R.uvBx = rlf(P[r].uvBx, j);
-						R.uvAy = rlf(P[r].uvAy, j);
-						R.uvBy = rlf(P[r].uvBy, j);
-						CVX_LMARK("runfetch_end");
-						drawRun(R, elementBoundsMin, elementBoundsMax, rli(runLen[r], j), rli(runCidx[r], j), columnColorsOff, rlu(faceColor[r], j), worldBoundsMin, worldBoundsMax);
+				if ((bits & (1u << (2 * r))) != 0u) {
+					int rbMin = rli(P[r].rbMinS, j), rbMax = rli(P[r].rbMaxS, j);
+					if (rbMax >= nextFreePixelMin && rbMin <= nextFreePixelMax) { // :505
+						CVX_LSTAT(7);
+						CVX_LMARK("sidereduce_begin");
+						CVX_LSEC(7);
+						lone_reduce_pixel_horizon<HI>(seen, omin, omax, rbMin, rbMax, nextFreePixelMin, nextFreePixelMax, frustumBoundsMin, frustumBoundsMax);
+						CVX_LMARK("sidereduce_end");
+						CVX_LSEC(8);
+						if (rbMin <= rbMax) {
+							sidePixels(rbMin, rbMax, rlf(P[r].boundsX, j), rlf(P[r].boundsY, j), rlf(P[r].uvAx, j), rlf(P[r].uvBx, j), rlf(P[r].uvAy, j), rlf(P[r].uvBy, j), rli(runLen[r], j), rli(runCidx[r], j),
+							           rlu(colorsOff, j));
+						}
+						if (nextFreePixelMin > nextFreePixelMax) { alive = false; return; } // :535-539
+						CVX_LMARK("sidepixels_end");
+						CVX_LSEC(6);
+					}
+				}
+				if ((bits & (2u << (2 * r))) != 0u) {
+					int rbMin = rli(P[r].rbMinF, j), rbMax = rli(P[r].rbMaxF, j);
+					if (rbMax >= nextFreePixelMin && rbMin <= nextFreePixelMax) { // :581
+						CVX_LSTAT(8);
+						CVX_LMARK("facereduce_begin");
+						CVX_LSEC(9);
+						lone_reduce_pixel_horizon<HI>(seen, omin, omax, rbMin, rbMax, nextFreePixelMin, nextFreePixelMax, frustumBoundsMin, frustumBoundsMax);
+						CVX_LMARK("facereduce_end");
+						CVX_LSEC(10);
+						if (rbMin <= rbMax) { facePixels(rbMin, rbMax, rlu(faceColor[r], j)); }
+						if (nextFreePixelMin > nextFreePixelMax) { alive = false; return; } // :604-608
+						CVX_LMARK("facepixels_end");
+						CVX_LSEC(6);
 					}
 				}
 			}
@@ -640,6 +668,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 		auto clipColumn = [&](int j) {
 			CVX_LSTAT(11);
 			CVX_LMARK("clip_begin");
+			CVX_LSEC(3);
 			const float dL = rlf(wDistLast, j), dN = rlf(wDistNext, j);
 			const float dist = roleNext ? dN : dL;
 			// :289-293 for this lane's intersection (x and z: the clip never looks at y)
@@ -689,6 +718,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 			CVX_LMARK("clip_end");
 			if (!CVX_USUAL(windowUntouched)) {
 				CVX_LSTAT(13);
+				CVX_LSEC(4);
 				const float mine = ptX / ptZ; // lanes: minLast, maxLast, minNext, maxNext
 				const float partner = quadSwapMax(mine);
 				const bool sw = roleMax ? mine < partner : partner < mine; // :339-346: max < min -> swap
@@ -714,10 +744,27 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 
 		// ---- one pass over the lanes >= from with the ray's current state: the cull of every column (:261-281) and whether any of its runs can touch
 		// the state (:461-475, :505, :549-565, :581).  `clipped` >= 0: that lane's column was just clipped (it is drawn with the clip's world bounds).
+		// which runs of the lane's column can touch the ray's state, given the column's world bounds (wbMin / wbMax) and the current window: bit 2r = the side
+		// of run r, bit 2r + 1 = its face, bit 31 = a column of the run list (looked at when its turn comes)
+		auto runTests = [&]() {
+			todo = (flags & CVX_LF_LISTED) != 0u ? 0x80000000u : 0u;
+#pragma unroll
+			for (int r = 0; r < 3; r++) {
+				if (r > 0 && !anyRun[r]) { continue; } // (wave-uniform: no column of the window has such a run)
+				const uint32_t f = flags >> (r * 8);
+				const float b = (float)runB[r], t = (float)runT[r];
+				const bool in = ((int)((f & CVX_LF_EXISTS) != 0u) & (int)!(b > wbMax) & (int)!(t < wbMin)) != 0;                                                                       // :461-475
+				const bool side = ((int)in & (int)((f & CVX_LF_SIDE) != 0u) & (int)(P[r].rbMaxS >= nextFreePixelMin) & (int)(P[r].rbMinS <= nextFreePixelMax)) != 0;                     // :505
+				const bool wanted = (((int)((f & CVX_LF_FACETOP) != 0u) & (int)!(t > wbMax)) | ((int)((f & CVX_LF_FACEBOTTOM) != 0u) & (int)!(b < wbMin))) != 0;                        // :549-565
+				const bool face = ((int)in & (int)wanted & (int)((f & CVX_LF_FACENEAR) != 0u) & (int)(P[r].rbMaxF >= nextFreePixelMin) & (int)(P[r].rbMinF <= nextFreePixelMax)) != 0; // :581
+				todo |= (side ? 1u << (2 * r) : 0u) | (face ? 2u << (2 * r) : 0u);
+			}
+		};
 		lanemask_t hits = 0ull, leftWorldMask = 0ull;
 		auto cullAndFilter = [&](int from, int clipped) {
 			CVX_LSTAT(14);
 			CVX_LMARK("filter_begin");
+			CVX_LSEC(5);
 			const float columnWorldMin = (float)(rec.y & 0xFFFFu);
 			const float columnWorldMax = (float)(rec.y >> 16);
 			const float newMax = posY + hw_max(frustumDirMaxWorld * wDistNext, frustumDirMaxWorld * wDistLast);
@@ -728,24 +775,15 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 			const bool draw = ((int)nonEmpty & (int)!leftWorld & (int)!noOverlap) != 0;
 			wbMin = own ? wbMin : newMin;
 			wbMax = own ? wbMax : newMax;
-			bool hit = (flags & CVX_LF_LISTED) != 0u; // (a column of the run list: looked at when its turn comes)
-#pragma unroll
-			for (int r = 0; r < 3; r++) {
-				if (r > 0 && !anyRun[r]) { continue; } // (wave-uniform: no column of the window has such a run)
-				const uint32_t f = flags >> (r * 8);
-				const float b = (float)runB[r], t = (float)runT[r];
-				const bool in = ((int)((f & CVX_LF_EXISTS) != 0u) & (int)!(b > wbMax) & (int)!(t < wbMin)) != 0;
-				const bool side = ((int)((f & CVX_LF_SIDE) != 0u) & (int)(P[r].rbMaxS >= nextFreePixelMin) & (int)(P[r].rbMinS <= nextFreePixelMax)) != 0;
-				const bool wanted = (((int)((f & CVX_LF_FACETOP) != 0u) & (int)!(t > wbMax)) | ((int)((f & CVX_LF_FACEBOTTOM) != 0u) & (int)!(b < wbMin))) != 0;
-				const bool face = ((int)wanted & (int)((f & CVX_LF_FACENEAR) != 0u) & (int)(P[r].rbMaxF >= nextFreePixelMin) & (int)(P[r].rbMinF <= nextFreePixelMax)) != 0;
-				hit = ((int)hit | ((int)in & ((int)side | (int)face))) != 0;
-			}
+			runTests();
 			const lanemask_t range = lanes_from(from);
-			hits = __ballot(draw && hit) & range;
+			hits = __ballot(draw && todo != 0u) & range;
 			leftWorldMask = __ballot(leftWorld) & range;
 			CVX_LMARK("filter_end");
+			CVX_LSEC(0);
 		};
 
+		CVX_LSEC(0);
 		// ---- the events of the window, in column order
 		int next = 0;         // first lane not yet looked at
 		bool hitsValid = false;
@@ -757,18 +795,22 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 				const int j = __ffsll((long long)rem) - 1;
 				if (rlf(wDistLast, j) > 2.0f) {
 					clipColumn(j);
+					CVX_LSEC(0);
 					if (!alive) { break; }
 					cullAndFilter(j, j);
 					hitsValid = true;
 					// the clipped column itself goes on to its element loop whatever the clip computed (also a direction that happens to BE the sentinel)
 					if ((hits >> j) & 1ull) {
 						processColumn(j);
+						CVX_LSEC(0);
 						if (frustumDirMaxWorld == CVX_FLOAT_EPSILON) { hitsValid = false; }
 					}
 					next = j + 1;
 				} else {
 					{ const bool mine = lane == j; wbMin = mine ? 0.0f : wbMin; wbMax = mine ? worldMaxY : wbMax; }
+					runTests();
 					processColumn(j);
+					CVX_LSEC(0);
 					next = j + 1;
 					hitsValid = false;
 				}
@@ -784,6 +826,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 				const int fh = h != 0ull ? __ffsll((long long)h) - 1 : CVX_WAVE, fl = l != 0ull ? __ffsll((long long)l) - 1 : CVX_WAVE;
 				if (fl < fh) { alive = false; break; } // :265-269: the frustum left the world
 				processColumn(fh);
+				CVX_LSEC(0);
 				next = fh + 1;
 				if (frustumDirMaxWorld == CVX_FLOAT_EPSILON) { hitsValid = false; } // a pixel was written: the directions are gone (:522,598)
 			}
@@ -831,8 +874,9 @@ __global__ __launch_bounds__(CVX_WAVE, CVX_LONE_WAVES_PER_SIMD) void lone_kernel
 	const gptr_tile tileOut = (gptr_tile)tile.out;
 	const uint32_t laneByteOff = (uint32_t)firstLane * 4u;
 #ifdef CVX_LONE_STATS
-	unsigned int stat_[32];
-	for (int i = 0; i < 32; i++) { stat_[i] = 0u; }
+	unsigned int stat_[48];
+	for (int i = 0; i < 48; i++) { stat_[i] = 0u; }
+	stat_[30] = (unsigned int)__builtin_amdgcn_s_memtime();
 #else
 	unsigned int *stat_ = nullptr;
 #endif
@@ -843,11 +887,13 @@ __global__ __launch_bounds__(CVX_WAVE, CVX_LONE_WAVES_PER_SIMD) void lone_kernel
 	}
 #ifdef CVX_LONE_STATS
 	stat_[16]++;
+	CVX_LSEC(0);
 	if (threadIdx.x == 0) {
-		for (int i = 0; i < 32; i++) { atomicAdd(&g_loneStats[i], (unsigned long long)stat_[i]); }
+		for (int i = 0; i < 48; i++) { atomicAdd(&g_loneStats[i], (unsigned long long)stat_[i]); }
 	}
 #endif
 	// WriteSkybox / WriteSkyboxFull (:699-716): every pixel of [omin, omax] not marked seen gets the skybox colour (lane = mask word)
+	CVX_LSEC(11);
 	{
 		const int w = seen.wordBase + seen.lane;
 		uint32_t todo = ~seen.w0 & range_mask_any(w, omin, omax);

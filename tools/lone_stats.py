@@ -24,7 +24,7 @@ ctx = gpu.Context(0)
 ctx.upload_world(ws)
 ctx.set_resolution(W, H)
 lib = ctypes.CDLL(os.environ["CVX_GPU_LIB"])
-out = (ctypes.c_uint64 * 32)()
+out = (ctypes.c_uint64 * 48)()
 lib.cvx_debug_lone_stats(out, 1)
 for g in range(poses):
     pos, eul = host.sample_benchmark_path(((g * 37) % 1000) / 1000 * host.BENCHMARK_PATH_LENGTH, ws.dims)
@@ -35,4 +35,11 @@ names = ["windows", "columns", "run projections (per window and run index)", "si
 print(f"per frame ({poses} frames {W}x{H} {world}):")
 for i, n in enumerate(names):
     print(f"  {n:50s} {out[i] / poses:12.1f}")
+sections = ["event loop / other", "window: DDA", "window: records + projections", "clip", "clip: window touched", "cull + filter", "column glue", "side: horizon", "side: pixels",
+            "face: horizon", "face: pixels", "skybox pass"]
+total = sum(out[32 + i] for i in range(len(sections)))
+if total:
+    print("share of wave cycles per section (s_memtime, -DCVX_LONE_TIMES):")
+    for i, n in enumerate(sections):
+        print(f"  {n:50s} {out[32 + i] / total * 100:6.2f} %   {out[32 + i] / poses / 1e6:8.2f} M cycles per frame")
 ctx.close()
