@@ -101,6 +101,7 @@ struct cvx_context {
 	int maxWaveMaskWords = 40 * CVX_WAVE; // LDS budget per wave: 10 KB = 16 waves per CU; wider tiles are cut into narrower waves
 	bool maxWaveMaskWordsAuto = true;     // ... chosen per launch by DrawBatch's cost model unless CVX_MAX_WAVE_MASK_WORDS pins it
 
+	int lonePixels = 0;              // lone_kernel: pixels of the longest window [origMin, origMax] of the launch (its LDS row)
 	int launchLone = 0;              // the current launch goes to lone_kernel (cvx_lone.h): 1 = one mask register, 2 = two (windows of more than 2048 pixels)
 	int loneMode = 1;                // 1: lone_kernel for launches of at most loneWaveBudget rays; experiment build: CVX_LONE=0 never, CVX_LONE=1 (-> 2) always
 	int loneWaveBudget = 16384;      // rays (= waves) up to which a launch goes to lone_kernel

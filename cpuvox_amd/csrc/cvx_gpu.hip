@@ -430,12 +430,13 @@ int Launch(cvx_context *ctx, int frameCount, int flags)
 		// kernel, so the tails of different frames overlap.  Its dynamic-LDS size is the largest mask any of its waves needs (DrawBatch).
 		const size_t ldsBytes = (size_t)std::max(ctx->ldsWordsNeeded, ctx->minMaskWords * CVX_WAVE) * sizeof(uint32_t);
 		dim3 grid((unsigned)nTiles), block(CVX_WAVE);
+		const size_t loneLdsBytes = (size_t)(CVX_WAVE + ctx->lonePixels) * sizeof(uint32_t); // lone_kernel: the merge buffer + the ray's pixel row
 		if (ctx->countersEnabled) {
 			hipLaunchKernelGGL((cvxk::render_kernel<true>), grid, block, ldsBytes, ctx->stream, ctx->devFrames, ctx->devTiles, ctx->devWorld, ctx->devCounters);
 		} else if (ctx->launchLone == 1) { // one wave per ray, lanes = columns (cvx_lone.h): the single interactive frame
-			hipLaunchKernelGGL((cvxk::lone_kernel<false>), grid, block, 0, ctx->stream, ctx->devFrames, ctx->devTiles, ctx->devWorld);
+			hipLaunchKernelGGL((cvxk::lone_kernel<false>), grid, block, loneLdsBytes, ctx->stream, ctx->devFrames, ctx->devTiles, ctx->devWorld);
 		} else if (ctx->launchLone == 2) { // ... windows of more than 2048 pixels (4K)
-			hipLaunchKernelGGL((cvxk::lone_kernel<true>), grid, block, 0, ctx->stream, ctx->devFrames, ctx->devTiles, ctx->devWorld);
+			hipLaunchKernelGGL((cvxk::lone_kernel<true>), grid, block, loneLdsBytes, ctx->stream, ctx->devFrames, ctx->devTiles, ctx->devWorld);
 		} else {
 			hipLaunchKernelGGL((cvxk::render_kernel<false>), grid, block, ldsBytes, ctx->stream, ctx->devFrames, ctx->devTiles, ctx->devWorld, ctx->devCounters);
 		}
@@ -767,6 +768,12 @@ int DrawBatch(cvx_context *ctx, int frameCount, const cvx_segment_data *segments
 				}
 			}
 			ctx->launchLone = ctx->maskWordsNeeded > CVX_WAVE ? 2 : 1;
+			ctx->lonePixels = 0;
+			for (const DevFrame &F : ctx->hostFrames) {
+				for (int sIdx = 0; sIdx < 4; sIdx++) {
+					if (F.seg[sIdx].rayCount > 0) { ctx->lonePixels = std::max(ctx->lonePixels, F.seg[sIdx].omax - F.seg[sIdx].omin + 1); }
+				}
+			}
 			ctx->ldsWordsNeeded = 0;
 			ctx->hostTiles.swap(rays);
 			return Launch(ctx, frameCount, flags);

@@ -285,7 +285,7 @@ __device__ __forceinline__ RunProj project_run(f3 camSpaceMinLast, f3 camSpaceMa
 // One ray: TraceToFirstColumnJob + ExecuteRay by one wave.
 // ---------------------------------------------------------------------------
 template <int DIR, bool HI>
-__device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegment &S, const DevWorld *__restrict__ world, int planeRayIndex, gptr_tile tileOut, uint32_t laneByteOff,
+__device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegment &S, const DevWorld *__restrict__ world, int planeRayIndex, uint32_t *pix /* LDS: pix[y] = pixel y of the ray's row */,
                                                LoneSeen &seen, uint32_t *merged /* 64 words of LDS */, unsigned int *stat_)
 {
 	(void)stat_;
@@ -529,7 +529,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 					if (CVX_RARE(!certain)) { row = tex_row_exact(y, boundsX, boundsY, uvAx, uvBx, uvAy, uvBy); }
 					const int colorIdx = m_clampi(row, 0, elementLength - 1) + elementColorsIndex;
 					const uint32_t c = ld_color(arena, columnColorsOff + ((uint32_t)colorIdx << L.colorShift));
-					st_pixel(tileOut, laneByteOff, y, c);
+					pix[y] = c;
 				}
 			}
 			lone_mark<HI>(seen, rbMin, rbMax);
@@ -543,7 +543,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 				CVX_LSTAT(5);
 				CVX_LSTAT_ADD(6, __popcll(todo));
 				frustumDirMaxWorld = CVX_FLOAT_EPSILON; // :598
-				if (__builtin_amdgcn_inverse_ballot_w64(todo)) { st_pixel(tileOut, laneByteOff, yb + lane, color); }
+				if (__builtin_amdgcn_inverse_ballot_w64(todo)) { pix[yb + lane] = color; }
 			}
 			lone_mark<HI>(seen, rbMin, rbMax);
 		};
@@ -588,6 +588,12 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 			CVX_LSTAT(9);
 			CVX_LMARK("process_begin");
 			CVX_LSEC(6);
+#ifdef CVX_LONE_STATS
+			{ // how often the window [nextFreePixelMin, Max] holds no seen pixel when a column is processed ("clean": every scan / unseen test is then trivial)
+				int n_ = __popc(seen.w0 & range_mask_any(seen.wordBase + lane, nextFreePixelMin, nextFreePixelMax)) + (HI ? __popc(seen.w1 & range_mask_any(seen.wordBase + 64 + lane, nextFreePixelMin, nextFreePixelMax)) : 0);
+				if (__ballot(n_ != 0) == 0ull) { CVX_LSTAT(17); }
+			}
+#endif
 			const uint32_t bits = rlu(todo, j);
 			if (CVX_RARE((bits & 0x80000000u) != 0u)) {
 				CVX_LSTAT(10);
@@ -859,7 +865,11 @@ template <bool HI>
 #endif
 __global__ __launch_bounds__(CVX_WAVE, CVX_LONE_WAVES_PER_SIMD) void lone_kernel(const DevFrame *__restrict__ frames, const DevTile *__restrict__ tiles, const DevWorld *__restrict__ world)
 {
-	__shared__ uint32_t merged[CVX_WAVE]; // the DDA's crossings in merged order (lone_trace_ray)
+	extern __shared__ uint32_t lds[]; // [0, 64): the DDA's crossings in merged order (lone_trace_ray); [64, 64 + omax - omin]: the ray's pixel row
+	uint32_t *merged = lds;
+#ifdef CVX_LONE_STATS
+	const unsigned long long waveStart_ = __builtin_amdgcn_s_memtime();
+#endif
 	const DevTile tile = tiles[blockIdx.x];
 	const DevFrame &F = frames[tile.frame];
 	const DevSegment &S = F.seg[tile.seg];
@@ -873,6 +883,12 @@ __global__ __launch_bounds__(CVX_WAVE, CVX_LONE_WAVES_PER_SIMD) void lone_kernel
 	seen.lane = (int)threadIdx.x;
 	const gptr_tile tileOut = (gptr_tile)tile.out;
 	const uint32_t laneByteOff = (uint32_t)firstLane * 4u;
+	// The ray's pixel row [omin, omax] is staged in LDS and written out once, at the end: gfx9 counts loads and stores in ONE counter (vmcnt), so a
+	// pixel store in the column loop would make every later wait for a colour load also wait for the store's acknowledgement from memory.  Staged, the
+	// loop's only vector-memory operations are loads, and the row's stores are issued back to back with nothing waiting for them.  Every pixel starts
+	// as the skybox colour (WriteSkybox / WriteSkyboxFull, :699-716: whatever is not written by a run).
+	uint32_t *pix = lds + CVX_WAVE - omin;
+	for (int y = omin + seen.lane; y <= omax; y += CVX_WAVE) { pix[y] = CVX_SKYBOX_ARGB; }
 #ifdef CVX_LONE_STATS
 	unsigned int stat_[48];
 	for (int i = 0; i < 48; i++) { stat_[i] = 0u; }
@@ -881,37 +897,24 @@ __global__ __launch_bounds__(CVX_WAVE, CVX_LONE_WAVES_PER_SIMD) void lone_kernel
 	unsigned int *stat_ = nullptr;
 #endif
 	if (F.inverse) { // RenderJob.Execute :174-178
-		lone_trace_ray<-1, HI>(F, S, world, planeRayIndex, tileOut, laneByteOff, seen, merged, stat_);
+		lone_trace_ray<-1, HI>(F, S, world, planeRayIndex, pix, seen, merged, stat_);
 	} else {
-		lone_trace_ray<1, HI>(F, S, world, planeRayIndex, tileOut, laneByteOff, seen, merged, stat_);
+		lone_trace_ray<1, HI>(F, S, world, planeRayIndex, pix, seen, merged, stat_);
 	}
 #ifdef CVX_LONE_STATS
 	stat_[16]++;
 	CVX_LSEC(0);
 	if (threadIdx.x == 0) {
-		for (int i = 0; i < 48; i++) { atomicAdd(&g_loneStats[i], (unsigned long long)stat_[i]); }
+		const unsigned long long life_ = __builtin_amdgcn_s_memtime() - waveStart_;
+		for (int i = 0; i < 48; i++) { if (i != 18 && i != 19 && i != 20) { atomicAdd(&g_loneStats[i], (unsigned long long)stat_[i]); } }
+		atomicAdd(&g_loneStats[18], life_);                 // sum of the waves' lives (clock ticks)
+		atomicMax(&g_loneStats[19], life_);                 // the longest
+		if (life_ == atomicMax(&g_loneStats[19], 0ull)) { g_loneStats[20] = stat_[1]; } // (columns of the longest wave so far: racy, diagnostic only)
 	}
 #endif
-	// WriteSkybox / WriteSkyboxFull (:699-716): every pixel of [omin, omax] not marked seen gets the skybox colour (lane = mask word)
+	// the row goes out: pixel y of this ray at tile row y (256 bytes per row, cvx_device.h)
 	CVX_LSEC(11);
-	{
-		const int w = seen.wordBase + seen.lane;
-		uint32_t todo = ~seen.w0 & range_mask_any(w, omin, omax);
-		while (todo != 0u) {
-			const int y = (w << 5) + (__ffs((int)todo) - 1);
-			todo &= todo - 1u;
-			st_pixel_stream(tileOut, laneByteOff, y, CVX_SKYBOX_ARGB);
-		}
-	}
-	if (HI) {
-		const int w = seen.wordBase + 64 + seen.lane;
-		uint32_t todo = ~seen.w1 & range_mask_any(w, omin, omax);
-		while (todo != 0u) {
-			const int y = (w << 5) + (__ffs((int)todo) - 1);
-			todo &= todo - 1u;
-			st_pixel_stream(tileOut, laneByteOff, y, CVX_SKYBOX_ARGB);
-		}
-	}
+	for (int y = omin + seen.lane; y <= omax; y += CVX_WAVE) { st_pixel(tileOut, laneByteOff, y, pix[y]); }
 }
 
 } // namespace cvxk

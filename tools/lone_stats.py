@@ -26,12 +26,23 @@ ctx.set_resolution(W, H)
 lib = ctypes.CDLL(os.environ["CVX_GPU_LIB"])
 out = (ctypes.c_uint64 * 48)()
 lib.cvx_debug_lone_stats(out, 1)
+acc = [0] * 48
+lives = []
 for g in range(poses):
     pos, eul = host.sample_benchmark_path(((g * 37) % 1000) / 1000 * host.BENCHMARK_PATH_LENGTH, ws.dims)
     ctx.draw_segments(host.setup_frame(host.camera_pose(pos, eul, W, H), lods, far, W, H, ws.dims[1]), 0)
-lib.cvx_debug_lone_stats(out, 0)
+    lib.cvx_debug_lone_stats(out, 1)
+    for i in range(48):
+        acc[i] += out[i]
+    lives.append((ctx.last_draw_ms(), out[19], out[18], out[16], out[20]))
+for i in range(48):
+    out[i] = acc[i]
+ms = sum(l[0] for l in lives) / poses
+ticks_per_ms = sum(l[1] for l in lives) / sum(l[0] for l in lives)  # (an upper bound of the clock: the longest wave cannot outlive the kernel)
+print(f"kernel {ms:.3f} ms per frame; longest wave / kernel: clock ticks per ms >= {ticks_per_ms:.0f}; sum of wave lives / (longest life x waves) = "
+      f"{sum(l[2] for l in lives) / sum(l[1] * l[3] for l in lives):.3f}; columns of the longest wave ~{sum(l[4] for l in lives) / poses:.0f}")
 names = ["windows", "columns", "run projections (per window and run index)", "side trips", "side pixels", "face trips", "face pixels", "side overlaps (:505)", "face overlaps (:581)",
-         "processColumn", "... listed", "clipColumn", "... general form", "... window touched", "cullAndFilter", "runs inside the world bounds", "rays"]
+         "processColumn", "... listed", "clipColumn", "... general form", "... window touched", "cullAndFilter", "runs inside the world bounds", "rays", "processColumn with a clean window"]
 print(f"per frame ({poses} frames {W}x{H} {world}):")
 for i, n in enumerate(names):
     print(f"  {n:50s} {out[i] / poses:12.1f}")
