@@ -1304,11 +1304,13 @@ int cvx_copy_rows(cvx_context *ctx, void *hipStream, int toPacked, int64_t spanC
 }
 
 #ifdef CVX_LONE_STATS /* diagnostic variant only (tools/lone_stats.py): event counts of the latency kernel, accumulated over all launches */
-int cvx_debug_lone_stats(uint64_t out[48], int reset)
+int cvx_debug_lone_stats(uint64_t out[96], int reset)
 {
 	unsigned long long tmp[48];
 	if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(tmp, HIP_SYMBOL(cvxk::g_loneStats), sizeof tmp) != hipSuccess) { return CVX_ERR_HIP; }
 	for (int i = 0; i < 48; i++) { out[i] = tmp[i]; }
+	if (hipMemcpyFromSymbol(tmp, HIP_SYMBOL(cvxk::g_loneLongest), sizeof tmp) != hipSuccess) { return CVX_ERR_HIP; }
+	for (int i = 0; i < 48; i++) { out[48 + i] = tmp[i]; }
 	if (reset) {
 		std::memset(tmp, 0, sizeof tmp);
 		if (hipMemcpyToSymbol(HIP_SYMBOL(cvxk::g_loneStats), tmp, sizeof tmp) != hipSuccess) { return CVX_ERR_HIP; }

@@ -43,6 +43,7 @@ typedef unsigned long long lanemask_t;
 #endif
 #ifdef CVX_LONE_STATS
 __device__ unsigned long long g_loneStats[48];
+__device__ unsigned long long g_loneLongest[48];
 #define CVX_LSTAT(n) (stat_[n]++)
 #define CVX_LSTAT_ADD(n, v) (stat_[n] += (unsigned int)(v))
 // section clock (s_memtime): the cycles since the last switch go to the section that was current; stat_[32 + section]
@@ -752,18 +753,40 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 		// the state (:461-475, :505, :549-565, :581).  `clipped` >= 0: that lane's column was just clipped (it is drawn with the clip's world bounds).
 		// which runs of the lane's column can touch the ray's state, given the column's world bounds (wbMin / wbMax) and the current window: bit 2r = the side
 		// of run r, bit 2r + 1 = its face, bit 31 = a column of the run list (looked at when its turn comes)
+		// which runs of the lane's column can touch the ray's state, given the column's world bounds (wbMin / wbMax) and the current window: bit 2r = the side
+		// of run r, bit 2r + 1 = its face, bit 31 = a column of the run list (looked at when its turn comes).
+		// A run's side / face has to overlap the window [nextFreePixelMin, Max] (:505 / :581) -- and to hold an UNSEEN pixel: ReducePixelHorizon (:660-697) moves
+		// a bound only when the range covers it (and the bounds are unseen pixels), the pixel loops only write unseen pixels.  More than two thirds of the
+		// overlapping runs of the benchmark world hold none (the far side of a floating slab whose near side is drawn).  So, unless the window holds no seen
+		// pixel at all (one ballot), the mask word of the first pixel of the run's clamped range (side and face together) comes from the lane that holds it
+		// (ds_bpermute); a range that goes on into a second word counts as writable (the column's turn in processColumn makes the exact tests either way).
 		auto runTests = [&]() {
 			todo = (flags & CVX_LF_LISTED) != 0u ? 0x80000000u : 0u;
+			bool windowClean = __ballot((seen.w0 & range_mask_any(seen.wordBase + lane, nextFreePixelMin, nextFreePixelMax)) != 0u) == 0ull;
+			if (HI) { windowClean = windowClean && __ballot((seen.w1 & range_mask_any(seen.wordBase + 64 + lane, nextFreePixelMin, nextFreePixelMax)) != 0u) == 0ull; }
 #pragma unroll
 			for (int r = 0; r < 3; r++) {
 				if (r > 0 && !anyRun[r]) { continue; } // (wave-uniform: no column of the window has such a run)
 				const uint32_t f = flags >> (r * 8);
 				const float b = (float)runB[r], t = (float)runT[r];
-				const bool in = ((int)((f & CVX_LF_EXISTS) != 0u) & (int)!(b > wbMax) & (int)!(t < wbMin)) != 0;                                                                       // :461-475
-				const bool side = ((int)in & (int)((f & CVX_LF_SIDE) != 0u) & (int)(P[r].rbMaxS >= nextFreePixelMin) & (int)(P[r].rbMinS <= nextFreePixelMax)) != 0;                     // :505
-				const bool wanted = (((int)((f & CVX_LF_FACETOP) != 0u) & (int)!(t > wbMax)) | ((int)((f & CVX_LF_FACEBOTTOM) != 0u) & (int)!(b < wbMin))) != 0;                        // :549-565
-				const bool face = ((int)in & (int)wanted & (int)((f & CVX_LF_FACENEAR) != 0u) & (int)(P[r].rbMaxF >= nextFreePixelMin) & (int)(P[r].rbMinF <= nextFreePixelMax)) != 0; // :581
-				todo |= (side ? 1u << (2 * r) : 0u) | (face ? 2u << (2 * r) : 0u);
+				const bool in = ((int)((f & CVX_LF_EXISTS) != 0u) & (int)!(b > wbMax) & (int)!(t < wbMin)) != 0;                                                  // :461-475
+				const int loS = max(P[r].rbMinS, nextFreePixelMin), hiS = min(P[r].rbMaxS, nextFreePixelMax), loF = max(P[r].rbMinF, nextFreePixelMin), hiF = min(P[r].rbMaxF, nextFreePixelMax);
+				const bool side = ((int)in & (int)((f & CVX_LF_SIDE) != 0u) & (int)(loS <= hiS)) != 0;                                                           // :505
+				const bool wanted = (((int)((f & CVX_LF_FACETOP) != 0u) & (int)!(t > wbMax)) | ((int)((f & CVX_LF_FACEBOTTOM) != 0u) & (int)!(b < wbMin))) != 0; // :549-565
+				const bool face = ((int)in & (int)wanted & (int)((f & CVX_LF_FACENEAR) != 0u) & (int)(loF <= hiF)) != 0;                                         // :581
+				bool writable = true;
+				if (!windowClean) {
+					const int lo = side ? (face ? min(loS, loF) : loS) : loF, hi = side ? (face ? max(hiS, hiF) : hiS) : hiF;
+					const int i = (lo >> 5) - seen.wordBase, first = lo & 31;
+					uint32_t word = (uint32_t)__builtin_amdgcn_ds_bpermute((i & 63) << 2, (int)seen.w0);
+					if (HI) {
+						const uint32_t word1 = (uint32_t)__builtin_amdgcn_ds_bpermute((i & 63) << 2, (int)seen.w1);
+						word = i < CVX_WAVE ? word : word1;
+					}
+					const int more = min(hi - lo, 31 - first); // pixels of the range in this word, less one
+					writable = ((int)((hi - lo) > more) | (int)(((~word >> first) << (31 - more)) != 0u)) != 0;
+				}
+				todo |= ((int)side & (int)writable ? 1u << (2 * r) : 0u) | ((int)face & (int)writable ? 2u << (2 * r) : 0u);
 			}
 		};
 		lanemask_t hits = 0ull, leftWorldMask = 0ull;
@@ -876,6 +899,9 @@ __global__ __launch_bounds__(CVX_WAVE, CVX_LONE_WAVES_PER_SIMD) void lone_kernel
 	const int firstLane = tile.lanes & 0xFF;
 	const int planeRayIndex = tile.tileInSeg * CVX_WAVE + firstLane; // RaySetupJob (:19-39)
 	if (planeRayIndex >= S.rayCount) { return; }
+#ifdef CVX_LONE_PRIO
+	if ((int)blockIdx.x < CVX_LONE_PRIO) { __builtin_amdgcn_s_setprio(3); } // (experiment: the longest rays of the launch first in their SIMD's issue arbitration)
+#endif
 	const int omin = S.omin, omax = S.omax;
 	LoneSeen seen;
 	seen.w0 = seen.w1 = 0u; // stackalloc is zero-initialised, :208
@@ -909,7 +935,10 @@ __global__ __launch_bounds__(CVX_WAVE, CVX_LONE_WAVES_PER_SIMD) void lone_kernel
 		for (int i = 0; i < 48; i++) { if (i != 18 && i != 19 && i != 20) { atomicAdd(&g_loneStats[i], (unsigned long long)stat_[i]); } }
 		atomicAdd(&g_loneStats[18], life_);                 // sum of the waves' lives (clock ticks)
 		atomicMax(&g_loneStats[19], life_);                 // the longest
-		if (life_ == atomicMax(&g_loneStats[19], 0ull)) { g_loneStats[20] = stat_[1]; } // (columns of the longest wave so far: racy, diagnostic only)
+		if (life_ == atomicMax(&g_loneStats[19], 0ull)) { // (the counters of the longest wave so far: racy, diagnostic only)
+			g_loneStats[20] = stat_[1];
+			for (int i = 0; i < 48; i++) { g_loneLongest[i] = stat_[i]; }
+		}
 	}
 #endif
 	// the row goes out: pixel y of this ray at tile row y (256 bytes per row, cvx_device.h)

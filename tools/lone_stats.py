@@ -24,9 +24,10 @@ ctx = gpu.Context(0)
 ctx.upload_world(ws)
 ctx.set_resolution(W, H)
 lib = ctypes.CDLL(os.environ["CVX_GPU_LIB"])
-out = (ctypes.c_uint64 * 48)()
+out = (ctypes.c_uint64 * 96)()
 lib.cvx_debug_lone_stats(out, 1)
 acc = [0] * 48
+longest = [0] * 48
 lives = []
 for g in range(poses):
     pos, eul = host.sample_benchmark_path(((g * 37) % 1000) / 1000 * host.BENCHMARK_PATH_LENGTH, ws.dims)
@@ -34,6 +35,7 @@ for g in range(poses):
     lib.cvx_debug_lone_stats(out, 1)
     for i in range(48):
         acc[i] += out[i]
+        longest[i] += out[48 + i]
     lives.append((ctx.last_draw_ms(), out[19], out[18], out[16], out[20]))
 for i in range(48):
     out[i] = acc[i]
@@ -45,12 +47,13 @@ names = ["windows", "columns", "run projections (per window and run index)", "si
          "processColumn", "... listed", "clipColumn", "... general form", "... window touched", "cullAndFilter", "runs inside the world bounds", "rays", "processColumn with a clean window"]
 print(f"per frame ({poses} frames {W}x{H} {world}):")
 for i, n in enumerate(names):
-    print(f"  {n:50s} {out[i] / poses:12.1f}")
+    print(f"  {n:50s} {out[i] / poses:12.1f}     longest wave: {longest[i] / poses:10.1f}")
 sections = ["event loop / other", "window: DDA", "window: records + projections", "clip", "clip: window touched", "cull + filter", "column glue", "side: horizon", "side: pixels",
             "face: horizon", "face: pixels", "skybox pass"]
 total = sum(out[32 + i] for i in range(len(sections)))
 if total:
     print("share of wave cycles per section (s_memtime, -DCVX_LONE_TIMES):")
+    ltotal = sum(longest[32 + i] for i in range(len(sections)))
     for i, n in enumerate(sections):
-        print(f"  {n:50s} {out[32 + i] / total * 100:6.2f} %   {out[32 + i] / poses / 1e6:8.2f} M cycles per frame")
+        print(f"  {n:50s} {out[32 + i] / total * 100:6.2f} %   longest wave: {longest[32 + i] / ltotal * 100:6.2f} %  {longest[32 + i] / poses / 1e3:8.1f} k ticks")
 ctx.close()
