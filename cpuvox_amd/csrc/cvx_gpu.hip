@@ -429,7 +429,7 @@ int Launch(cvx_context *ctx, int frameCount, int flags)
 		// ONE launch, all frames of the batch in it: the iteration direction (RenderJob.Execute :174-178) is a wave-uniform runtime switch inside the
 		// kernel, so the tails of different frames overlap.  Its dynamic-LDS size is the largest mask any of its waves needs (DrawBatch).
 		const size_t ldsBytes = (size_t)std::max(ctx->ldsWordsNeeded, ctx->minMaskWords * CVX_WAVE) * sizeof(uint32_t);
-		dim3 grid((unsigned)nTiles), block(CVX_WAVE);
+		dim3 grid((unsigned)(ctx->launchLone ? nTiles * CVX_WAVE : nTiles)), block(CVX_WAVE);
 		const size_t loneLdsBytes = (size_t)(CVX_WAVE + ctx->lonePixels) * sizeof(uint32_t); // lone_kernel: the merge buffer + the ray's pixel row
 		if (ctx->countersEnabled) {
 			hipLaunchKernelGGL((cvxk::render_kernel<true>), grid, block, ldsBytes, ctx->stream, ctx->devFrames, ctx->devTiles, ctx->devWorld, ctx->devCounters);
@@ -756,17 +756,11 @@ int DrawBatch(cvx_context *ctx, int frameCount, const cvx_segment_data *segments
 		// (cvx_lone.h): one wave per RAY, its lanes the ray's next 64 columns.  Its mask lives in one or two vector registers: windows of up to 4096 pixels.
 		ctx->launchLone = 0;
 		if (!ctx->countersEnabled && ctx->maskWordsNeeded <= 2 * CVX_WAVE && (ctx->loneMode == 2 || (ctx->loneMode == 1 && n * (size_t)CVX_WAVE <= (size_t)ctx->loneWaveBudget)) && n > 0) {
-			std::vector<DevTile> rays;
-			rays.reserve(n * (size_t)CVX_WAVE);
-			for (size_t i = 0; i < n; i++) {
-				DevTile t = ctx->hostTiles[order[i]];
-				const DevSegment &S = ctx->hostFrames[(size_t)t.frame].seg[t.seg];
-				const int raysOfTile = std::min(CVX_WAVE, S.rayCount - t.tileInSeg * CVX_WAVE);
-				for (int k = 0; k < raysOfTile; k++) {
-					t.lanes = k | (1 << 8) | (6 << 16); // (the sub-tile form of one ray: firstLane | laneCount << 8 | dupShift << 16)
-					rays.push_back(t);
-				}
-			}
+			// (one workgroup per RAY: the kernel takes tile blockIdx / 64, ray blockIdx % 64 of it -- the tile list goes to the device as it is, longest tiles first)
+			std::vector<DevTile> sortedTiles;
+			sortedTiles.reserve(n);
+			for (size_t i = 0; i < n; i++) { sortedTiles.push_back(ctx->hostTiles[order[i]]); }
+			ctx->hostTiles.swap(sortedTiles);
 			ctx->launchLone = ctx->maskWordsNeeded > CVX_WAVE ? 2 : 1;
 			ctx->lonePixels = 0;
 			for (const DevFrame &F : ctx->hostFrames) {
@@ -775,7 +769,6 @@ int DrawBatch(cvx_context *ctx, int frameCount, const cvx_segment_data *segments
 				}
 			}
 			ctx->ldsWordsNeeded = 0;
-			ctx->hostTiles.swap(rays);
 			return Launch(ctx, frameCount, flags);
 		}
 		int split = 1;

@@ -82,11 +82,22 @@ struct LoneSeen {
 	int wordBase, lane;
 };
 
+// mask word `i` (0 .. 127, relative to wordBase) as a wave-uniform scalar; words the instance does not hold read as "all seen"
+template <bool HI>
+__device__ __forceinline__ uint32_t lone_word(const LoneSeen &s, int i)
+{
+	const uint32_t a = rlu(s.w0, i & 63);
+	if (!HI) { return i < 64 ? a : 0xFFFFFFFFu; }
+	const uint32_t b = rlu(s.w1, i & 63);
+	return i < 64 ? a : (i < 128 ? b : 0xFFFFFFFFu);
+}
+
 // first unseen pixel >= start, or omax + 1; start unchanged when start > omax (the reference's while loop at :407 / :678 does not run then)
 template <bool HI>
 __device__ __forceinline__ int lone_scan_up(const LoneSeen &s, int start, int omax)
 {
 	if (start > omax) { return start; }
+	if (((lone_word<HI>(s, (start >> 5) - s.wordBase) >> (start & 31)) & 1u) == 0u) { return start; } // (the usual case: the pixel right above the run is unseen)
 	const uint32_t m0 = ~s.w0 & range_mask_any(s.wordBase + s.lane, start, omax);
 	const lanemask_t b0 = __ballot(m0 != 0u);
 	if (b0 != 0ull) {
@@ -109,6 +120,7 @@ template <bool HI>
 __device__ __forceinline__ int lone_scan_down(const LoneSeen &s, int start, int omin)
 {
 	if (start < omin) { return start; }
+	if (((lone_word<HI>(s, (start >> 5) - s.wordBase) >> (start & 31)) & 1u) == 0u) { return start; } // (the usual case: the pixel right below the run is unseen)
 	if (HI) {
 		const uint32_t m1 = ~s.w1 & range_mask_any(s.wordBase + 64 + s.lane, omin, start);
 		const lanemask_t b1 = __ballot(m1 != 0u);
@@ -145,16 +157,6 @@ __device__ __forceinline__ void lone_reduce_pixel_horizon(const LoneSeen &s, int
 	}
 }
 
-// mask word `i` (0 .. 127, relative to wordBase) as a wave-uniform scalar; words the instance does not hold read as "all seen"
-template <bool HI>
-__device__ __forceinline__ uint32_t lone_word(const LoneSeen &s, int i)
-{
-	const uint32_t a = rlu(s.w0, i & 63);
-	if (!HI) { return i < 64 ? a : 0xFFFFFFFFu; }
-	const uint32_t b = rlu(s.w1, i & 63);
-	return i < 64 ? a : (i < 128 ? b : 0xFFFFFFFFu);
-}
-
 // the pixels yb .. yb + 63 that are NOT yet seen, as a lane mask (bit p = pixel yb + p); yb >= omin
 template <bool HI>
 __device__ __forceinline__ lanemask_t lone_unseen64(const LoneSeen &s, int yb)
@@ -163,6 +165,15 @@ __device__ __forceinline__ lanemask_t lone_unseen64(const LoneSeen &s, int yb)
 	const unsigned long long a = lone_word<HI>(s, i), b = lone_word<HI>(s, i + 1), c = lone_word<HI>(s, i + 2);
 	const unsigned long long lo = (a | (b << 32)) >> sh, hi = (b | (c << 32)) >> sh;
 	return ~((lo & 0xFFFFFFFFull) | (hi << 32));
+}
+
+// ... of the n <= 64 pixels yb .. yb + n - 1 (the usual case, a few pixels inside one mask word, reads that one word)
+template <bool HI>
+__device__ __forceinline__ lanemask_t lone_unseen(const LoneSeen &s, int yb, int n)
+{
+	const int sh = yb & 31;
+	if (sh + n <= 32) { return (lanemask_t)((~lone_word<HI>(s, (yb >> 5) - s.wordBase) >> sh) & (0xFFFFFFFFu >> (32 - n))); }
+	return lone_unseen64<HI>(s, yb) & (n >= CVX_WAVE ? ~0ull : ((1ull << n) - 1ull));
 }
 
 // marks the pixels [lo, hi] as seen (every word at once: lane = word)
@@ -518,7 +529,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 			const TexRun texRun = tex_run(boundsX, boundsY, uvAx, uvBx, uvAy, uvBy);
 			for (int yb = rbMin; yb <= rbMax; yb += CVX_WAVE) {
 				const int n = min(CVX_WAVE, rbMax - yb + 1);
-				const lanemask_t todo = lone_unseen64<HI>(seen, yb) & (n >= CVX_WAVE ? ~0ull : ((1ull << n) - 1ull));
+				const lanemask_t todo = lone_unseen<HI>(seen, yb, n);
 				if (todo == 0ull) { continue; }
 				CVX_LSTAT(3);
 				CVX_LSTAT_ADD(4, __popcll(todo));
@@ -539,7 +550,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 		auto facePixels = [&](int rbMin, int rbMax, uint32_t color) {
 			for (int yb = rbMin; yb <= rbMax; yb += CVX_WAVE) {
 				const int n = min(CVX_WAVE, rbMax - yb + 1);
-				const lanemask_t todo = lone_unseen64<HI>(seen, yb) & (n >= CVX_WAVE ? ~0ull : ((1ull << n) - 1ull));
+				const lanemask_t todo = lone_unseen<HI>(seen, yb, n);
 				if (todo == 0ull) { continue; }
 				CVX_LSTAT(5);
 				CVX_LSTAT_ADD(6, __popcll(todo));
@@ -879,7 +890,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 }
 
 // ---------------------------------------------------------------------------
-// lone kernel: grid = rays (one DevTile with laneCount 1 each, cvx_gpu.hip DrawBatch), block = 64 (one wave), no LDS.
+// lone kernel: grid = 64 x tiles (workgroup b renders ray b % 64 of tile b / 64; cvx_gpu.hip DrawBatch), block = 64 (one wave).
 // HI: windows of more than 2048 pixels ([origMin, origMax] spans more than 64 mask words: 4K) carry a second mask register.
 // ---------------------------------------------------------------------------
 template <bool HI>
@@ -893,10 +904,10 @@ __global__ __launch_bounds__(CVX_WAVE, CVX_LONE_WAVES_PER_SIMD) void lone_kernel
 #ifdef CVX_LONE_STATS
 	const unsigned long long waveStart_ = __builtin_amdgcn_s_memtime();
 #endif
-	const DevTile tile = tiles[blockIdx.x];
+	const DevTile tile = tiles[blockIdx.x >> 6];
 	const DevFrame &F = frames[tile.frame];
 	const DevSegment &S = F.seg[tile.seg];
-	const int firstLane = tile.lanes & 0xFF;
+	const int firstLane = (int)(blockIdx.x & 63u);
 	const int planeRayIndex = tile.tileInSeg * CVX_WAVE + firstLane; // RaySetupJob (:19-39)
 	if (planeRayIndex >= S.rayCount) { return; }
 #ifdef CVX_LONE_PRIO
