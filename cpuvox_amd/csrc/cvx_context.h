@@ -103,8 +103,11 @@ struct cvx_context {
 
 	int lonePixels = 0;              // lone_kernel: pixels of the longest window [origMin, origMax] of the launch (its LDS row)
 	int launchLone = 0;              // the current launch goes to lone_kernel (cvx_lone.h): 1 = one mask register, 2 = two (windows of more than 2048 pixels)
-	int loneMode = 1;                // 1: lone_kernel for launches of at most loneWaveBudget rays; experiment build: CVX_LONE=0 never, CVX_LONE=1 (-> 2) always
-	int loneWaveBudget = 16384;      // rays (= waves) up to which a launch goes to lone_kernel
+#ifndef CVX_LONE_DEFAULT_MODE
+#define CVX_LONE_DEFAULT_MODE 1
+#endif
+	int loneMode = CVX_LONE_DEFAULT_MODE; // 1: lone_kernel for launches of at most loneWaveBudget rays; 0 never, 2 always (experiment build: CVX_LONE=0 / 1; variants: -DCVX_LONE_DEFAULT_MODE)
+	int loneWaveBudget = 8192;       // rays (= waves, tiles x 64) up to which a launch goes to lone_kernel: two 1080p frames still win there, three lose (profiles/r06_latency.md)
 
 	int shardIndex = 0, shardCount = 1;
 	bool countersEnabled = false;

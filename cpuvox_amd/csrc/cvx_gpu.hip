@@ -632,6 +632,14 @@ int cvx_bind_raybuffers(cvx_context *ctx, void *topDown, int64_t topDownBytes, v
 	return CVX_OK;
 }
 
+int cvx_set_latency_kernel(cvx_context *ctx, int mode)
+{
+	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }
+	if (mode != CVX_LATENCY_AUTO && mode != CVX_LATENCY_NEVER && mode != CVX_LATENCY_ALWAYS) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "bad latency-kernel mode %d", mode); }
+	ctx->loneMode = mode == CVX_LATENCY_AUTO ? 1 : (mode == CVX_LATENCY_NEVER ? 0 : 2);
+	return CVX_OK;
+}
+
 int cvx_set_shard(cvx_context *ctx, int shardIndex, int shardCount)
 {
 	if (!ctx) { return CVX_ERR_INVALID_ARGUMENT; }

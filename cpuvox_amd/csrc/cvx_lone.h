@@ -841,6 +841,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 					hitsValid = true;
 					// the clipped column itself goes on to its element loop whatever the clip computed (also a direction that happens to BE the sentinel)
 					if ((hits >> j) & 1ull) {
+						CVX_LSTAT(21);
 						processColumn(j);
 						CVX_LSEC(0);
 						if (frustumDirMaxWorld == CVX_FLOAT_EPSILON) { hitsValid = false; }

@@ -21,11 +21,12 @@ RAYBUFFER_TOPDOWN = 0
 RAYBUFFER_LEFTRIGHT = 1
 DRAW_SYNC = 0
 DRAW_ASYNC = 1
+LATENCY_AUTO, LATENCY_NEVER, LATENCY_ALWAYS = 0, 1, 2  # cvx_set_latency_kernel
 
 # every symbol include/cpuvox_gpu.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "cvx_create", "cvx_destroy", "cvx_last_error", "cvx_set_stream", "cvx_world_upload", "cvx_set_resolution",
-    "cvx_set_buffer_count", "cvx_draw_segments", "cvx_draw_segments_batch", "cvx_set_shard", "cvx_synchronize",
+    "cvx_set_buffer_count", "cvx_draw_segments", "cvx_draw_segments_batch", "cvx_set_shard", "cvx_set_latency_kernel", "cvx_synchronize",
     "cvx_clear_raybuffer", "cvx_read_raybuffer", "cvx_blit_segments", "cvx_blit_segments_batch", "cvx_raybuffer_device_ptr",
     "cvx_screen_device_ptr", "cvx_last_draw_ms", "cvx_enable_counters", "cvx_get_counters",
     "cvx_get_raybuffer_layout", "cvx_version", "cvx_bind_raybuffers", "cvx_draw_time_stats", "cvx_copy_rows", "cvx_draw_segments_placed",
@@ -116,6 +117,7 @@ def _bind(path: str) -> C.CDLL:
         L.cvx_draw_segments_batch.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
         L.cvx_draw_segments_placed.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int]
         L.cvx_set_shard.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.cvx_set_latency_kernel.argtypes = [C.c_void_p, C.c_int]
         L.cvx_synchronize.argtypes = [C.c_void_p]
         L.cvx_clear_raybuffer.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint32]
         L.cvx_read_raybuffer.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -247,6 +249,10 @@ class Context:
 
     def set_shard(self, index: int, count: int) -> None:
         self._check(lib().cvx_set_shard(self._h, index, count))
+
+    def set_latency_kernel(self, mode: int) -> None:
+        """Which kernel a draw goes to: LATENCY_AUTO (few rays -> one wave per ray), LATENCY_NEVER, LATENCY_ALWAYS (include/cpuvox_gpu.h)."""
+        self._check(lib().cvx_set_latency_kernel(self._h, mode))
 
     def enable_counters(self, enable: bool) -> None:
         self._check(lib().cvx_enable_counters(self._h, int(enable)))

@@ -78,6 +78,8 @@ namespace CpuVox.Gpu
 		[DllImport(Lib)] public static extern int cvx_draw_segments(IntPtr ctx, SegmentData* segments, CameraData* camera, int screenWidth, int screenHeight, float* vanishingPointScreenSpace, int bufferIndex, int flags);
 		[DllImport(Lib)] public static extern int cvx_draw_segments_batch(IntPtr ctx, int frameCount, SegmentData* segments, CameraData* cameras, int screenWidth, int screenHeight, float* vanishingPoints, int firstBufferIndex, int flags);
 		[DllImport(Lib)] public static extern int cvx_set_shard(IntPtr ctx, int shardIndex, int shardCount);
+		public const int CVX_LATENCY_AUTO = 0, CVX_LATENCY_NEVER = 1, CVX_LATENCY_ALWAYS = 2;
+		[DllImport(Lib)] public static extern int cvx_set_latency_kernel(IntPtr ctx, int mode);
 		[DllImport(Lib)] public static extern int cvx_synchronize(IntPtr ctx);
 		[DllImport(Lib)] public static extern int cvx_clear_raybuffer(IntPtr ctx, int bufferIndex, int which, uint argb);
 		[DllImport(Lib)] public static extern int cvx_read_raybuffer(IntPtr ctx, int bufferIndex, int which, int firstRay, int rayCount, void* dst);

@@ -50,9 +50,14 @@ def _render_build_matches(ctx, name, fr, o_td, o_lr):
     """The SHIPPED kernel (render_kernel<false>, counters off: it leaves a finished ray once per column and takes the
     automatic LDS-budget / sub-tile path) drawn into the same buffer again and compared with the same oracle output."""
     ctx.enable_counters(False)
-    ctx.clear_raybuffers(0, CLEAR)
-    ctx.draw_segments(fr, 0)
-    _compare(name + " [rendering build]", fr, ctx.read_raybuffer(0, 0), ctx.read_raybuffer(0, 1), o_td, o_lr)
+    # ... through the kernel a caller gets (AUTO), and pinned to each of the two (include/cpuvox_gpu.h, cvx_set_latency_kernel): the batch kernel, lanes =
+    # rays, and the latency kernel, one wave per ray with its lanes the ray's next 64 columns (4K rows take its two-register mask)
+    for label, mode in (("automatic", gpu.LATENCY_AUTO), ("batch kernel", gpu.LATENCY_NEVER), ("latency kernel", gpu.LATENCY_ALWAYS)):
+        ctx.set_latency_kernel(mode)
+        ctx.clear_raybuffers(0, CLEAR)
+        ctx.draw_segments(fr, 0)
+        ctx.set_latency_kernel(gpu.LATENCY_AUTO)
+        _compare(f"{name} [rendering build, {label}]", fr, ctx.read_raybuffer(0, 0), ctx.read_raybuffer(0, 1), o_td, o_lr)
 
 
 def _same_counters(name, gc, oc):

@@ -48,13 +48,20 @@ def exp_library(monkeypatch):
     gpu.use_library(None)
 
 
-def _render_gpu(ctx, fr, counters=False):
+def _render_gpu(ctx, fr, counters=False, latency=gpu.LATENCY_AUTO):
     ctx.enable_counters(counters)
+    ctx.set_latency_kernel(latency)
     ctx.clear_raybuffers(0, CLEAR)
     ctx.draw_segments(fr, 0)
+    ctx.set_latency_kernel(gpu.LATENCY_AUTO)
     td = ctx.read_raybuffer(0, gpu.RAYBUFFER_TOPDOWN)
     lr = ctx.read_raybuffer(0, gpu.RAYBUFFER_LEFTRIGHT)
     return td, lr
+
+
+# a draw goes to one of two kernels (include/cpuvox_gpu.h, cvx_set_latency_kernel): the batch kernel (lanes = rays, cvx_kernels.h) or the latency kernel
+# (one wave per ray, lanes = columns, cvx_lone.h).  Both must give the oracle's raybuffers bit for bit; AUTO is what a caller gets.
+BOTH_KERNELS = [("batch kernel", gpu.LATENCY_NEVER), ("latency kernel", gpu.LATENCY_ALWAYS)]
 
 
 def _compare(name, fr, g_td, g_lr, o_td, o_lr):
@@ -91,6 +98,21 @@ def test_scene_bit_exact_vs_oracle_and_golden(contexts, name):
     assert gold["counters"]["S"] == gc.S and gold["counters"]["P"] == gc.P
 
 
+@pytest.mark.parametrize("name", list(scenes.SCENES))
+def test_scene_bit_exact_through_both_kernels(contexts, name):
+    """Every scene with the counters off (the shipped kernels), once pinned to the batch kernel and once to the latency kernel: the oracle's raybuffers
+    bit for bit, nothing outside the rows / pixel windows of the frame touched."""
+    ws, fr, W, H = scenes.scene_frame(name)
+    ctx = contexts(scenes.SCENES[name][0], W, H)
+    o_td, o_lr, _ = O.draw_segments(ws, fr, W, H, clear=CLEAR, counters=False)
+    n_td, n_lr = scenes.used_rows(fr)
+    for label, mode in BOTH_KERNELS + [("automatic choice", gpu.LATENCY_AUTO)]:
+        g_td, g_lr = _render_gpu(ctx, fr, latency=mode)
+        _compare(f"{name} [{label}]", fr, g_td, g_lr, o_td, o_lr)
+        assert (g_td[n_td:] == CLEAR).all() and (g_lr[n_lr:] == CLEAR).all(), label
+        assert ((g_td[:n_td] == CLEAR) == (o_td[:n_td] == CLEAR)).all() and ((g_lr[:n_lr] == CLEAR) == (o_lr[:n_lr] == CLEAR)).all(), label
+
+
 def test_counters_off_gives_same_pixels(contexts):
     name = "proc256_t04_lod8"
     ws, fr, W, H = scenes.scene_frame(name)
@@ -112,9 +134,10 @@ def test_random_poses_fuzz(contexts):
         pos = [frac[k] * ws.dims[k] for k in range(3)]
         eul = [rng.uniform(-89, 89), rng.uniform(0, 360), rng.choice([0.0, 0.0, rng.uniform(0, 360)])]
         fr = scenes.make_frame(ws, W, H, pos, eul, lod_error=float(rng.choice([1.0, 3.0, 9.0])))
-        g_td, g_lr = _render_gpu(ctx, fr)
         o_td, o_lr, _ = O.draw_segments(ws, fr, W, H, clear=CLEAR, counters=False)
-        _compare(f"fuzz{i} pos={pos} eul={eul}", fr, g_td, g_lr, o_td, o_lr)
+        for label, mode in BOTH_KERNELS:
+            g_td, g_lr = _render_gpu(ctx, fr, latency=mode)
+            _compare(f"fuzz{i} [{label}] pos={pos} eul={eul}", fr, g_td, g_lr, o_td, o_lr)
 
 
 def test_random_poses_fuzz_mill_and_odd_resolutions(contexts):
@@ -128,9 +151,10 @@ def test_random_poses_fuzz_mill_and_odd_resolutions(contexts):
             pos = [frac[k] * ws.dims[k] for k in range(3)]
             eul = [rng.uniform(-89, 89), rng.uniform(0, 360), rng.choice([0.0, rng.uniform(0, 360)])]
             fr = scenes.make_frame(ws, W, H, pos, eul)
-            g_td, g_lr = _render_gpu(ctx, fr)
             o_td, o_lr, _ = O.draw_segments(ws, fr, W, H, clear=CLEAR, counters=False)
-            _compare(f"millfuzz {W}x{H} #{i} pos={pos} eul={eul}", fr, g_td, g_lr, o_td, o_lr)
+            for label, mode in BOTH_KERNELS:
+                g_td, g_lr = _render_gpu(ctx, fr, latency=mode)
+                _compare(f"millfuzz {W}x{H} #{i} [{label}] pos={pos} eul={eul}", fr, g_td, g_lr, o_td, o_lr)
 
 
 def test_batch_equals_single_frames(contexts):

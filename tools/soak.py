@@ -1,5 +1,7 @@
 """Parity soak (not part of the test-suite): many random camera poses, GPU raybuffers and counters against the CPU oracle.
-Usage: python tools/soak.py [poses per case]"""
+Usage: python tools/soak.py [poses per case]   random poses over four worlds: the counting build, then the shipped build pinned to the batch kernel AND
+                                                  to the latency kernel (cvx_set_latency_kernel), each against the oracle
+       python tools/soak.py bench                 the 1000 benchmark poses as batches (batch kernel) and as single blocking draws (latency kernel)"""
 import os
 import sys
 
@@ -40,8 +42,18 @@ if len(sys.argv) > 1 and sys.argv[1] == "bench":
             if not (np.array_equal(g_td, o_td[:n_td]) and np.array_equal(g_lr, o_lr[:n_lr])):
                 bad += 1
                 print("MISMATCH benchmark pose", first + b)
+            # ... and the reference's call pattern: one blocking draw of this frame alone (the latency kernel, cvx_lone.h)
+            ctx.set_latency_kernel(gpu.LATENCY_ALWAYS)
+            ctx.clear_raybuffers(b, 0x9314FFFF)
+            ctx.draw_segments(fr, b)
+            ctx.set_latency_kernel(gpu.LATENCY_AUTO)
+            l_td = ctx.read_raybuffer(b, gpu.RAYBUFFER_TOPDOWN, 0, n_td)
+            l_lr = ctx.read_raybuffer(b, gpu.RAYBUFFER_LEFTRIGHT, 0, n_lr)
+            if not (np.array_equal(l_td, o_td[:n_td]) and np.array_equal(l_lr, o_lr[:n_lr])):
+                bad += 1
+                print("MISMATCH benchmark pose (latency kernel)", first + b)
         print(f"benchmark poses {first}..{first + 99}: {bad} mismatches so far", flush=True)
-    print(f"soak (benchmark path, proc2048 @ {W}x{H}): 1000 poses, {bad} mismatches")
+    print(f"soak (benchmark path, proc2048 @ {W}x{H}): 1000 poses as batches (batch kernel) + 1000 single draws (latency kernel), {bad} mismatches")
     sys.exit(1 if bad else 0)
 CLEAR = 0x9314FFFF
 rng = np.random.default_rng(20261003)
@@ -66,13 +78,16 @@ for world, W, H, lod_error in (("proc1024", 1920, 1080, 1.0), ("proc512", 1280, 
         n_td, n_lr = scenes.used_rows(fr)
         ok = np.array_equal(g_td[:n_td], o_td[:n_td]) and np.array_equal(g_lr[:n_lr], o_lr[:n_lr]) and \
             (c.S, c.E, c.C, c.P, c.R) == (oc.S, oc.E, oc.C, oc.P, oc.R)
-        # ... and the rendering build (render_kernel<false>), which leaves a finished ray at other points
+        # ... and the shipped build: the batch kernel (render_kernel<false>, which leaves a finished ray at other points) and the latency kernel (lone_kernel)
         ctx.enable_counters(False)
-        ctx.clear_raybuffers(1, CLEAR)
-        ctx.draw_segments(fr, 1)
-        r_td = ctx.read_raybuffer(1, gpu.RAYBUFFER_TOPDOWN)
-        r_lr = ctx.read_raybuffer(1, gpu.RAYBUFFER_LEFTRIGHT)
-        ok = ok and np.array_equal(r_td[:n_td], o_td[:n_td]) and np.array_equal(r_lr[:n_lr], o_lr[:n_lr])
+        for mode in (gpu.LATENCY_NEVER, gpu.LATENCY_ALWAYS):
+            ctx.set_latency_kernel(mode)
+            ctx.clear_raybuffers(1, CLEAR)
+            ctx.draw_segments(fr, 1)
+            r_td = ctx.read_raybuffer(1, gpu.RAYBUFFER_TOPDOWN)
+            r_lr = ctx.read_raybuffer(1, gpu.RAYBUFFER_LEFTRIGHT)
+            ok = ok and np.array_equal(r_td[:n_td], o_td[:n_td]) and np.array_equal(r_lr[:n_lr], o_lr[:n_lr])
+        ctx.set_latency_kernel(gpu.LATENCY_AUTO)
         total += 1
         if (i + 1) % 1000 == 0:
             print(f"  {world}: {i + 1} poses, {bad} mismatches so far", flush=True)
