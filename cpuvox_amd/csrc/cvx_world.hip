@@ -248,9 +248,13 @@ int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byt
 namespace {
 
 // Validates a world blob (every column, like cvx_world_upload) and copies it to the device.
-int UploadSourceBlob(cvx_context *ctx, const void *storage, int64_t byteLength, int dimX, int dimY, int dimZ, int lod, int columnCount, uint8_t **dSrc)
+// *elementsOfColumns (optional) receives what the columns hold when each is counted by itself -- RunCount runs + two guards + the colours its solid runs
+// address, summed over the columns: a number the blob's pool size says nothing about when several headers share one storageOffset.
+int UploadSourceBlob(cvx_context *ctx, const void *storage, int64_t byteLength, int dimX, int dimY, int dimZ, int lod, int columnCount, uint8_t **dSrc,
+                     int64_t *elementsOfColumns = nullptr)
 {
 	*dSrc = nullptr;
+	if (elementsOfColumns) { *elementsOfColumns = 0; }
 	if (!storage) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "bad arguments"); }
 	if (!IsPow2(dimX) || !IsPow2(dimY) || !IsPow2(dimZ) || dimY > 65536) {
 		return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "world dimensions must be powers of two (WordBuilder.cs:30), Y <= 65536");
@@ -268,8 +272,10 @@ int UploadSourceBlob(cvx_context *ctx, const void *storage, int64_t byteLength, 
 	for (int64_t i = 0; i < usedColumns; i++) {
 		if (src[i].runCount == 0) { continue; }
 		size_t solid = 0;
-		const int rc = ValidateColumn(ctx, i, src[i], elements, elementCount, dimY >> lod, &solid);
+		int64_t colours = 0;
+		const int rc = ValidateColumn(ctx, i, src[i], elements, elementCount, dimY >> lod, &solid, &colours);
 		if (rc != CVX_OK) { return rc; }
+		if (elementsOfColumns) { *elementsOfColumns += (int64_t)src[i].runCount + 2 + colours; }
 	}
 	CVX_HIP(ctx, hipSetDevice(ctx->device));
 	CVX_HIP(ctx, hipMalloc((void **)dSrc, (size_t)byteLength));
@@ -426,11 +432,13 @@ int DownsampleDevice(cvx_context *ctx, const uint8_t *dSrc, int dimX, int dimY, 
 // reference's "first inserted voxel keeps its alpha").  Same kernels, same two passes around the same scan per level as DownsampleDevice, but no host
 // round trip between them: the element pools are sized by a bound instead of by the scanned total -- a target column needs at most the elements of its
 // four sources + 2 (its solid runs are unions of theirs, one more air run, two guards; halving Y never adds runs), so level j has at most
-// elements(LOD 0) + 2 (columns(1) + ... + columns(j)) < elements(LOD 0) + columns(LOD 0) of them -- and every error is looked at once, at the end.
+// elements(LOD 0) + 2 (columns(1) + ... + columns(j)) < elements(LOD 0) + columns(LOD 0) of them, elements(LOD 0) counted COLUMN BY COLUMN (a blob whose
+// headers share pool regions holds more elements than its pool) -- and every error is looked at once, at the end.
+// Device memory: per level the bound x 4 bytes, + two tables of per-voxel sums of the bound x 24 bytes: ~17 x the LOD 0 blob for five levels, ~19 x for seven.
 // Levels above `kMaxChainLevel` (channel sums of 2^24 voxels x 255 no longer fit 32 bits) are left to DownsampleDevice.
 constexpr int kMaxChainLevel = 7;
 
-int BuildLodChainDevice(cvx_context *ctx, const uint8_t *dSrc, int64_t byteLength, int dimX, int dimY, int dimZ, int columnCount, int levelCount,
+int BuildLodChainDevice(cvx_context *ctx, const uint8_t *dSrc, int64_t elementsOfColumns, int dimX, int dimY, int dimZ, int columnCount, int levelCount,
                         void **outStorage, int64_t *outByteLength, int32_t *outColumnCount, float *outDeviceMs)
 {
 	struct Level {
@@ -459,15 +467,21 @@ int BuildLodChainDevice(cvx_context *ctx, const uint8_t *dSrc, int64_t byteLengt
 		for (void *p : host) { std::free(p); }
 		return rc;
 	};
+	// (running out of device memory is CVX_ERR_CAPACITY: the caller then builds level by level, which needs a fraction of it; any other HIP error is an error)
 #define CVX_CH(call)                                                                                                                          \
 	do {                                                                                                                                      \
 		hipError_t e_ = (call);                                                                                                               \
-		if (e_ != hipSuccess) { return fail(Fail(ctx, CVX_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__)); } \
+		if (e_ != hipSuccess) {                                                                                                               \
+			if (e_ == hipErrorOutOfMemory) { (void)hipGetLastError(); }                                                                       \
+			return fail(Fail(ctx, e_ == hipErrorOutOfMemory ? CVX_ERR_CAPACITY : CVX_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__)); \
+		}                                                                                                                                     \
 	} while (0)
 	const int64_t usedColumns0 = (int64_t)dimX * dimZ;
-	const int64_t elements0 = (byteLength - (int64_t)columnCount * 12) / 4;
-	const int64_t elementBound = elements0 + usedColumns0; // (see above; >= 1)
-	if (elementBound > 0x7FFFFFFFll) { return Fail(ctx, CVX_ERR_CAPACITY, "Only supports up to 2^31 elements (World.cs:355-357)"); }
+	// The bound counts every source column by itself (UploadSourceBlob: runs + two guards + colours, summed over the columns), NOT the blob's pool: headers
+	// may share one storageOffset and runs of a column may share colours (the reference's loader accepts both, and so does cvx_world_upload), and then a
+	// small pool stands for many elements -- every one of which the next level may need a place for.
+	const int64_t elementBound = elementsOfColumns + usedColumns0; // (see above; >= 1)
+	if (elementBound > 0x7FFFFFFFll) { return Fail(ctx, CVX_ERR_CAPACITY, "the chain's pools would pass 2^31 elements (World.cs:355-357 per level): level by level instead"); }
 	for (int j = 1; j <= levelCount; j++) {
 		Level &l = L[(size_t)j];
 		if ((dimX >> j) < 1 || (dimY >> j) < 1 || (dimZ >> j) < 1) { return fail(Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "LOD %d out of range for these dimensions", j)); }
@@ -592,14 +606,21 @@ int cvx_world_build_lods(cvx_context *ctx, const void *storage, int64_t byteLeng
 	if (!outStorage || !outByteLength || !outColumnCount || levelCount < 1 || levelCount > 15) { return Fail(ctx, CVX_ERR_INVALID_ARGUMENT, "bad arguments"); }
 	for (int i = 0; i < levelCount; i++) { outStorage[i] = nullptr; }
 	uint8_t *dSrc = nullptr;
-	int rc = UploadSourceBlob(ctx, storage, byteLength, dimX, dimY, dimZ, 0, columnCount, &dSrc);
+	int64_t elementsOfColumns = 0;
+	int rc = UploadSourceBlob(ctx, storage, byteLength, dimX, dimY, dimZ, 0, columnCount, &dSrc, &elementsOfColumns);
 	if (rc != CVX_OK) { return rc; }
 	// levels 1 .. min(levelCount, 7) as one chain that reads LOD 0 once; anything above from LOD 0 directly
 	float totalMs = 0.0f;
 	const int chained = std::min(levelCount, kMaxChainLevel);
-	rc = BuildLodChainDevice(ctx, dSrc, byteLength, dimX, dimY, dimZ, columnCount, chained, outStorage, outByteLength, outColumnCount, &totalMs);
+	rc = BuildLodChainDevice(ctx, dSrc, elementsOfColumns, dimX, dimY, dimZ, columnCount, chained, outStorage, outByteLength, outColumnCount, &totalMs);
+#ifdef CVX_EXPERIMENTS
+	if (std::getenv("CVX_LOD_CHAIN_FAILS")) { // (diagnostics: the level-by-level fallback below, as if the chain's pools had not fitted)
+		for (int i = 0; i < chained; i++) { std::free(outStorage[i]); outStorage[i] = nullptr; }
+		rc = CVX_ERR_CAPACITY;
+	}
+#endif
 	int first = chained;
-	if (rc == CVX_ERR_HIP) { // (e.g. not enough device memory for the chain's pools, ~7 x the LOD 0 blob: level by level from LOD 0 instead, like rounds 1-4)
+	if (rc == CVX_ERR_CAPACITY) { // the chain's pools (~17 x the LOD 0 blob) did not fit the device memory or the 2^31 elements of a level: level by level from LOD 0 instead, like rounds 1-4
 		(void)hipGetLastError();
 		for (int i = 0; i < levelCount; i++) { outStorage[i] = nullptr; }
 		totalMs = 0.0f;

@@ -102,6 +102,9 @@ int cvx_set_stream(cvx_context *ctx, void *hipStream);
  * ownership of storage.  Dimensions must be powers of two (WordBuilder.cs:30),
  * X and Z at most 32768, Y at most 65536 (8192 x 8192 columns already fill the
  * 4 GiB of device tables the 32-bit offsets of the kernel address).
+ * Per level: fewer than 2^30 pool entries (CVX_ERR_CAPACITY beyond); on the device the colours are kept in blocks
+ * of 4 x 8 columns, each as deep as its tallest column -- ~2.5 x the colours of a terrain, at most 2^29 slots, and a level
+ * whose blocks would take more than 4 x its colours keeps them column after column; all levels together within the 4 GiB arena.
  */
 int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byteLength,
                      int dimX, int dimY, int dimZ, int columnCount);
@@ -317,7 +320,9 @@ int cvx_world_downsample(cvx_context *ctx, const void *storage, int64_t byteLeng
  * each blob is released with cvx_free.  outDeviceMs (may be NULL) = device time of the whole chain.  LOD 0 is read ONCE: level 1
  * is built from its colours, every further level (up to 7) from the level before it through exact per-voxel sums, which gives the
  * bytes of `DownSample(i)` applied to LOD 0 (integer averages of the LOD-0 voxels, the first inserted voxel's alpha); levels above 7
- * are built from LOD 0 directly like cvx_world_downsample does.  Device memory while it runs: ~7 x the LOD 0 blob. */
+ * are built from LOD 0 directly like cvx_world_downsample does.  Device memory while it runs: per level 4 bytes x (the elements of the LOD 0
+ * columns, counted column by column, + its columns) and two tables of per-voxel sums of 24 bytes x the same -- ~17 x the LOD 0 blob for five
+ * levels, ~19 x for seven; when that does not fit (or passes 2^31 elements) the levels are built one by one from LOD 0, which needs ~2 x. */
 int cvx_world_build_lods(cvx_context *ctx, const void *storage, int64_t byteLength, int dimX, int dimY, int dimZ, int columnCount, int levelCount,
                          void **outStorage, int64_t *outByteLength, int32_t *outColumnCount, float *outDeviceMs);
 void cvx_free(void *p);

@@ -328,6 +328,70 @@ def test_lod_chain_reads_lod0_once_and_matches_the_host_build(dims, seed, column
         ctx.close()
 
 
+def test_lod_chain_of_a_blob_whose_columns_share_one_pool_region():
+    """the chain sized its pools from the SIZE of the LOD 0 pool; a blob whose headers share one storageOffset (the reference's loader
+    accepts it, and so does cvx_world_upload) has a tiny pool and needs big levels -- the write pass then ran past its buffers.  The bound now counts
+    every column by itself.  Every column of this world IS one column (all headers point at the same run list); the chain must give the bytes of the
+    level-by-level entry point (which allocates from the scanned totals) for every level."""
+    dims = (64, 128, 64)
+    x, y, z, argb = _random_alpha_world(dims, 31, 600, 4)
+    base = host.WorldSet.from_voxels(dims, x, y, z, argb, threads=4)
+    blob = np.array(base.storage(0), dtype=np.uint8, copy=True)
+    columns = dims[0] * dims[2]
+    header = np.dtype({"names": ["off", "rc", "mn", "mx"], "formats": ["<i4", "<u2", "<u2", "<u2"], "offsets": [0, 4, 6, 8], "itemsize": 12})
+    hdr = blob[:columns * 12].view(header)
+    el = blob[columns * 12:].view(np.dtype([("ci", "<i2"), ("len", "<i2")]))
+    tallest = int(np.argmax(hdr["rc"]))
+    h = hdr[tallest].copy()
+    runs = el[h["off"] + 1: h["off"] + 1 + h["rc"]]
+    colours = int(max((r["ci"] + r["len"] for r in runs if r["ci"] >= 0), default=0))
+    block = int(h["rc"]) + 2 + colours  # guard, runs, guard, colours
+    assert h["rc"] >= 3 and colours >= 20
+    pool = np.array(el[h["off"]: h["off"] + block], copy=True)
+    aliased = np.zeros(columns * 12 + block * 4, dtype=np.uint8)
+    ah = aliased[:columns * 12].view(header)
+    ah["off"], ah["rc"], ah["mn"], ah["mx"] = 0, h["rc"], h["mn"], h["mx"]  # 4096 headers, ONE pool region of `block` entries
+    aliased[columns * 12:] = pool.view(np.uint8)
+    assert columns * block > 4 * (block + columns), "the old bound (pool + columns) must be far too small for level 1"
+    ws = host.WorldSet.from_blobs(dims, [aliased])
+    ctx = gpu.Context(0)
+    try:
+        rebuilt = ctx.build_lods(ws, levels=6)
+        for lod in range(1, 6):
+            want, columns_, voxels, ms = ctx.downsample(ws, 0, lod)
+            got = rebuilt.storage(lod)
+            assert np.array_equal(got, np.frombuffer(want, dtype=np.uint8)), f"LOD {lod}: chain and level-by-level build differ"
+            assert voxels > 0
+    finally:
+        ctx.close()
+
+
+def test_lod_chain_deeper_than_its_sums_reach_and_its_fallback(exp_library):
+    """ADVICE r5: cvx_world_build_lods chains levels 1 .. 7 (the channel sums of deeper levels do not fit 32 bits) and builds the rest from LOD 0 directly;
+    when the chain's pools do not fit the device it builds every level that way.  Both hand-overs against the level-by-level entry point: a 256^3 world
+    with all 8 levels, and the same with the chain made to fail (CVX_LOD_CHAIN_FAILS, experiment build)."""
+    ws = scenes.load_world("proc256")
+    blobs = {}
+    for fails in (False, True):
+        if fails:
+            exp_library.setenv("CVX_LOD_CHAIN_FAILS", "1")
+        ctx = gpu.Context(0)
+        try:
+            rebuilt = ctx.build_lods(ws, levels=9)  # LOD 1 .. 8 (256 >> 8 = 1 column)
+            assert rebuilt.lod_count == 9
+            for lod in range(1, 9):
+                got = np.array(rebuilt.storage(lod), copy=True)
+                if not fails:
+                    want, columns_, voxels, ms = ctx.downsample(ws, 0, lod)
+                    assert np.array_equal(got, np.frombuffer(want, dtype=np.uint8)), f"LOD {lod}: chain and level-by-level build differ"
+                    blobs[lod] = got
+                else:
+                    assert np.array_equal(got, blobs[lod]), f"LOD {lod}: the fallback differs from the chain"
+        finally:
+            ctx.close()
+    exp_library.delenv("CVX_LOD_CHAIN_FAILS")
+
+
 @pytest.mark.parametrize("split", [1, 2, 16, 64])
 def test_sub_tile_split_is_invisible(split, exp_library):
     """Small batches are rendered with tiles cut into sub-tiles of 64 / split rays per wave (DrawBatch); the raybuffers and the
@@ -638,9 +702,9 @@ def test_foreign_blob_columns_go_through_the_run_list():
             fr = scenes.make_frame(ws, W, H, pos, eul)
             directions.add(bool(fr.camera.InverseElementIterationDirection))
             o_td, o_lr, cnt = O.draw_segments(ws, fr, W, H, clear=CLEAR)
-            for counting in (True, False):
-                g_td, g_lr = _render_gpu(ctx, fr, counters=counting)
-                _compare(f"foreign blob pos={pos} eul={eul} counting={counting}", fr, g_td, g_lr, o_td, o_lr)
+            for counting, label, mode in [(True, "counting build", gpu.LATENCY_AUTO)] + [(False, l, m) for l, m in BOTH_KERNELS]:
+                g_td, g_lr = _render_gpu(ctx, fr, counters=counting, latency=mode)
+                _compare(f"foreign blob pos={pos} eul={eul} [{label}]", fr, g_td, g_lr, o_td, o_lr)
                 if counting:
                     gc = ctx.counters()
                     assert (gc.S, gc.E, gc.C, gc.P, gc.R) == (cnt.S, cnt.E, cnt.C, cnt.P, cnt.R), (gc.as_dict(), cnt.as_dict())
