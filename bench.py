@@ -524,6 +524,25 @@ def main():
             else:
                 fetch, how = 2.0 * fetch_raw, "2 x FETCH_SIZE (every read request of this kernel is a 128-byte line tallied at 64 bytes)"
             launches = max(1, k_draws)
+            if all(k in counters for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_VALU_TRANS_F32", "GRBM_GUI_ACTIVE")):
+                # The roof the kernel is actually under: instruction ISSUE.  Executed instructions per launch (SQ_INSTS_*, the same counter
+                # passes) x the issue prices tools/valu_rate.hip measures on gfx950 at this occupancy (profiles/r04_valu_rate.txt, r05_valu_rate_salu_mix.txt:
+                # a vector instruction 2.25 cycles of its SIMD, v_rcp_f32 8.1 .. 13.2, a scalar instruction or branch 1.0 .. 2.25 -- hidden behind another
+                # wave's vector issue or not --, an LDS / vector-memory instruction 2.3) against the SIMD cycles the launch had: GRBM_GUI_ACTIVE / 8 XCDs x
+                # 1024 SIMDs.  (profiles/r05_issue_model.md is the same model on the exact per-block instruction counts.)
+                trans, valu = counters["SQ_INSTS_VALU_TRANS_F32"], counters["SQ_INSTS_VALU"] - counters["SQ_INSTS_VALU_TRANS_F32"]
+                scalar = counters["SQ_INSTS_SALU"] + counters["SQ_INSTS_BRANCH"]
+                mem = sum(counters.get(k, 0.0) for k in ("SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"))
+                simd_cycles = counters["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0
+                lo = (2.25 * valu + 8.1 * trans + 1.0 * scalar + 2.3 * mem) / simd_cycles
+                hi = (2.25 * valu + 13.2 * trans + 2.25 * scalar + 2.3 * mem) / simd_cycles
+                result["roofline"]["secondary"] = {
+                    "bound": "valu_issue", "frac": round((lo + hi) / 2.0, 4), "frac_range": [round(lo, 4), round(hi, 4)],
+                    "instructions_per_launch": {"vector": int(valu + trans), "v_rcp_f32": int(trans), "scalar_and_branch": int(scalar), "lds_and_vector_memory": int(mem)},
+                    "simd_cycles_per_launch": int(simd_cycles),
+                    "what": "executed instructions x measured issue prices / SIMD cycles of the launch: the share of the launch the SIMDs' issue ports are busy (the kernel's "
+                            "arithmetic is the reference's IEEE-exact f32 with divisions; no dense contraction, so no MFMA roof applies)",
+                }
             pixel_bytes = 4 * sum(pixels[s] for s in steps) / launches
             result["roofline"]["traffic"] = int(fetch + write)
             result["roofline"]["traffic_detail"] = {
@@ -612,9 +631,40 @@ def main():
             events[-1].synchronize()
             dt2 = time.perf_counter() - t0
             ctx.set_stream(None)
+            # ... the same blocking calls pinned to the batch kernel (what rounds 1-5 ran a single frame on), and the curve: ms per blocking launch of n frames
+            # with the library's own kernel choice (the latency kernel up to 8192 rays per launch, the batch kernel beyond)
+            ctx.set_latency_kernel(gpu.LATENCY_NEVER)
+            t0 = time.perf_counter()
+            for k in range(K):
+                ctx.draw_packed(packed1[k], k % 2, gpu.DRAW_SYNC)
+            dt_batch = time.perf_counter() - t0
+            ctx.set_latency_kernel(gpu.LATENCY_AUTO)
+            curve = {}
+            for n in (1, 2, 4, 8, 16, 64):
+                if n > F or n > K:
+                    continue
+                packs = [ctx.pack_batch(singles[i:i + n]) for i in range(0, K - n + 1, n)]
+                ctx.draw_packed(packs[0], 0, gpu.DRAW_SYNC)
+                t0 = time.perf_counter()
+                for pk in packs:
+                    ctx.draw_packed(pk, 0, gpu.DRAW_SYNC)
+                curve[str(n)] = round((time.perf_counter() - t0) / len(packs) * 1e3, 4)
+            # two of the single frames back through the latency kernel for the parity leg below
+            for k in (0, K // 2):
+                ctx.set_latency_kernel(gpu.LATENCY_ALWAYS)
+                ctx.draw_packed(packed1[k], 0, gpu.DRAW_SYNC)
+                ctx.set_latency_kernel(gpu.LATENCY_AUTO)
+                rc = [max(0, sg.RayCount) for sg in singles[k].segments]
+                parity_frames.append((f"latency kernel, pose {(k * POSE_STRIDE) % POSES}", singles[k], ctx.read_raybuffer(0, gpu.RAYBUFFER_TOPDOWN, 0, rc[0] + rc[1]),
+                                      ctx.read_raybuffer(0, gpu.RAYBUFFER_LEFTRIGHT, 0, rc[2] + rc[3])))
+            result["fps_per_frame_latency"] = round(K / dt, 1)
+            result["latency_curve"] = {"ms_per_launch_by_frames": curve, "what": "wall ms of ONE blocking cvx_draw_segments_batch of n frames (the bench poses), mean over the launches; "
+                                       "automatic kernel choice (cvx_set_latency_kernel AUTO)"}
             result["latency"] = {
                 "frames": 1, "ms": round(dt / K * 1e3, 4), "fps": round(K / dt, 1), "mrays": round(rays1 / dt / 1e6, 3),
+                "kernel": "cvxk::lone_kernel (one wave per ray, lanes = the ray's next 64 columns: csrc/cvx_lone.h)",
                 "kernel_ms": round(k_ms1 / max(1, n1), 4),
+                "ms_batch_kernel": round(dt_batch / K * 1e3, 4),
                 "ms_max": round(per_frame[worst] * 1e3, 4), "fps_min": round(1.0 / per_frame[worst], 1), "worst_pose": (worst * POSE_STRIDE) % POSES,
                 "ms_p95": round(sorted(per_frame)[min(K - 1, (95 * K) // 100)] * 1e3, 4),  # (ms_max is one wall-clock sample: a host hiccup shows up there)
                 "pipelined_2deep": {"ms": round(dt2 / K * 1e3, 4), "fps": round(K / dt2, 1), "mrays": round(rays1 / dt2 / 1e6, 3)},
@@ -810,7 +860,8 @@ def cpu_baseline(ws, frames, W, H, budget_s: float, parity_frames=()):
             parity["pixels_differing"] += int((a != e).sum())
         parity["frames"].append(b)
     parity["ok"] = parity["pixels_differing"] == 0 and parity["pixels_compared"] > 0
-    parity["what"] = "frames of the last timed step (buffer indices above): device raybuffers vs the CPU oracle, every pixel the frame writes"
+    parity["what"] = ("frames of the last timed step (buffer indices above: the batch kernel) and two of the single-frame draws (the latency kernel): device raybuffers vs the CPU "
+                      "oracle, every pixel the frame writes")
     return baseline, parity
 
 
