@@ -61,9 +61,10 @@ def parse_args():
     ap.add_argument("--pmc-csv", default=None, help="counter summary of a rocprofv3 --pmc run of THIS command (tools/pmc_passes.sh + "
                     "tools/pmc_aggregate.py): fills roofline.traffic from FETCH_SIZE + WRITE_SIZE; without it traffic is null")
     ap.add_argument("--comm-timeout", type=float, default=180.0, help="N > 1: seconds cvx_comm_create may wait for the peers (then exit code 4)")
-    ap.add_argument("--gather", choices=("raybuffer", "image"), default="raybuffer",
+    ap.add_argument("--gather", choices=("raybuffer", "image", "auto"), default="raybuffer",
                     help="N > 1: what travels to the display rank of a frame -- the other ranks' raybuffer tile rows (BASELINE.json's north_star; default) or "
-                         "their pixels of the finished image (cvx_image_*: each rank runs Phase 2 for its own tiles; W*H*4 bytes per frame in total)")
+                         "their pixels of the finished image (cvx_image_*: each rank runs Phase 2 for its own tiles; W*H*4 bytes per frame in total); "
+                         "auto = whichever of the two puts fewer bytes on the wire for the frames of step 0 (rank 0 decides, every rank follows)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; 'gloo' = single-GPU rehearsal of the N > 1 path "
                     "(all ranks share the visible GPUs, tiles travel through host memory)")
     return ap.parse_args()
@@ -201,6 +202,21 @@ def main():
     ctx.set_resolution(W, H)
     packed = [ctx.pack_batch(frames) for frames in steps_frames]
 
+    gather_choice = None
+    if sharded and args.gather == "auto":
+        # what each gather would put on the wire for the frames of step 0 (host arithmetic + one tile census on the device): the smaller one is taken
+        from cpuvox_amd import dist as cdist0
+
+        rb_bytes = cdist0.ShardPlan(steps_frames[0], W, H, rank, N).send_total * 256
+        ip0 = gpu.ImagePlan(ctx, packed[0], W, H, rank, N)
+        choice = [None]
+        if rank == 0:
+            choice[0] = choose_gather(rb_bytes, ip0.send_pixels * 4)
+        dist.broadcast_object_list(choice, src=0)
+        gather_choice = dict(choice[0], raybuffer_bytes_this_rank=int(rb_bytes), image_bytes_this_rank=int(ip0.send_pixels * 4))
+        args.gather = choice[0]["gather"]
+        del ip0
+
     plans = tile_outs = None
     send = disp = None
     s_render = s_exchange = None
@@ -330,6 +346,44 @@ def main():
         lod_visits.append(list(c.lodVisits))
     ctx.enable_counters(False)
 
+    def exchange_step(s: int, par: int):
+        """The exchange of step s (its tiles lie in the areas of parity `par`), enqueued on the current stream (s_exchange)."""
+        if image_mode:
+            ip = img_plans[s]
+            ip.pack(ctx, s_exchange.cuda_stream, img_store[par].data_ptr(), img_send[par].data_ptr(), img_images[par].data_ptr())
+            if comm:
+                ip.exchange(ctx, comm, s_exchange.cuda_stream, img_send[par].data_ptr(), img_recv[par].data_ptr())
+            else:
+                image_exchange_torch(ip, img_send[par], img_recv[par])
+            ip.unpack(ctx, s_exchange.cuda_stream, img_recv[par].data_ptr(), img_images[par].data_ptr())
+        elif comm:
+            native_plans[s].exchange(ctx, comm, s_exchange.cuda_stream, send[par].data_ptr(), disp[par].data_ptr())
+        else:
+            for req in plans[s].exchange(send[par], disp[par]):
+                req.wait()
+
+    def alone(what: str, s: int, repeats: int = 2):
+        """One step's render, or one step's exchange, with nothing else on the GPU: wall ms between barriers, max over the ranks, best of `repeats`
+        (untimed extras after the measured region: what the step costs when the two do NOT overlap)."""
+        best = None
+        for _ in range(repeats):
+            barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            if what == "render":
+                draw(s, gpu.DRAW_ASYNC)
+                ctx.synchronize()
+            else:
+                with torch.cuda.stream(s_exchange):
+                    exchange_step(s, s % 2)
+                s_exchange.synchronize()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            tmax = torch.tensor([dt], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            best = float(tmax.item()) if best is None else min(best, float(tmax.item()))
+        return best * 1e3
+
     def run_region(first: int, last: int, overlap: bool):
         """Steps [first, last): render (+ exchange).  Returns after everything has completed on this rank."""
         ev_done = {}
@@ -345,19 +399,7 @@ def main():
             ev_render.record(s_render)
             s_exchange.wait_event(ev_render)
             with torch.cuda.stream(s_exchange):
-                if image_mode:
-                    ip = img_plans[s]
-                    ip.pack(ctx, s_exchange.cuda_stream, img_store[par].data_ptr(), img_send[par].data_ptr(), img_images[par].data_ptr())
-                    if comm:
-                        ip.exchange(ctx, comm, s_exchange.cuda_stream, img_send[par].data_ptr(), img_recv[par].data_ptr())
-                    else:
-                        image_exchange_torch(ip, img_send[par], img_recv[par])
-                    ip.unpack(ctx, s_exchange.cuda_stream, img_recv[par].data_ptr(), img_images[par].data_ptr())
-                elif comm:
-                    native_plans[s].exchange(ctx, comm, s_exchange.cuda_stream, send[par].data_ptr(), disp[par].data_ptr())
-                else:
-                    for req in plans[s].exchange(send[par], disp[par]):
-                        req.wait()
+                exchange_step(s, par)
                 ev_done[s] = torch.cuda.Event()
                 ev_done[s].record(s_exchange)
             if not overlap:
@@ -436,6 +478,15 @@ def main():
             k_ms_total, k_draws = ctx.draw_time_stats(reset=True)
             exchange_verified = verify_exchange(total_steps - 1)
 
+    breakdown = None
+    if sharded and not args.no_exchange:
+        # The first multi-GPU line has to explain itself: the last step's render alone, its exchange alone, and what the overlap hid
+        last_step = total_steps - 1
+        render_alone = alone("render", last_step)
+        exchange_alone = alone("exchange", last_step)
+        per_gpu_bytes = (int(np.mean([p.send_pixels for p in img_plans]) * 4) if image_mode else int(np.mean([p.send_total for p in plans]) * 256))
+        breakdown = scaling_breakdown(elapsed / args.steps * 1e3, render_alone, exchange_alone, per_gpu_bytes, N)
+
     steps = range(args.warmup, total_steps)
     total_rays = sum(rays_per_step[s] for s in steps)  # whole job: every ray of every frame is rendered by exactly one GPU
     total_frames = G * args.steps
@@ -484,6 +535,7 @@ def main():
             "exchange_verified": exchange_verified,
             "exchange_path": exchange_path,
             "gather": args.gather if sharded else None,
+            "gather_auto": gather_choice,
             "exchange_bytes_per_step_per_gpu": (int(np.mean([p.send_pixels for p in img_plans]) * 4) if image_mode else int(np.mean([p.send_total for p in plans]) * 256)) if sharded else 0,
             "world_dims": list(dims),
             "lod_distances": lods,
@@ -504,6 +556,8 @@ def main():
         },
     }
 
+    if breakdown:
+        result.update(breakdown)
     if not args.pmc_csv and N == 1:
         args.pmc_csv = find_counter_summary(args)
     if args.pmc_csv:
@@ -695,6 +749,35 @@ def main():
         dist.destroy_process_group()
     if parity_failed:
         raise SystemExit("bench.py: the GPU raybuffers of the timed frames differ from the CPU oracle")
+
+
+XGMI_LINK_GBPS = 153.0  # one xGMI link of an MI355X (7 per GPU, point to point)
+
+
+def scaling_breakdown(ms_per_step, render_ms_alone, exchange_ms_alone, exchange_bytes_per_gpu, n_gpus):
+    """Keys an N > 1 line carries so that it explains itself: what a step's render and a step's exchange cost on their own, how much of the cheaper one
+    the overlap hid (1 = the step took max(render, exchange), 0 = their sum), and what the payload would take on the wire -- every peer pair has its
+    own xGMI link, so a GPU's (N - 1) transfers run side by side and the bound is ONE peer's share over ONE link."""
+    hidden = render_ms_alone + exchange_ms_alone - ms_per_step
+    smaller = min(render_ms_alone, exchange_ms_alone)
+    per_peer = exchange_bytes_per_gpu / max(1, n_gpus - 1)
+    return {
+        "render_ms_alone": round(render_ms_alone, 4),
+        "exchange_ms_alone": round(exchange_ms_alone, 4),
+        "overlap_efficiency": round(max(0.0, min(1.0, hidden / smaller)), 4) if smaller > 0 else None,
+        "payload_ms_per_link_predicted": round(per_peer / (XGMI_LINK_GBPS * 1e9) * 1e3, 4),
+        "exchange_effective_gbps_per_link": round(per_peer / (exchange_ms_alone * 1e-3) / 1e9, 2) if exchange_ms_alone > 0 else None,
+        "scaling_notes": "render_ms_alone / exchange_ms_alone: one untimed extra step each after the measured region (max over ranks); overlap_efficiency = "
+                         "(render + exchange - ms_per_step) / min(render, exchange); payload_ms_per_link_predicted = this GPU's bytes per peer and step / 153 GB/s.  "
+                         "RCCL's send / receive kernels take CUs from a render kernel that is bound by instruction issue: NCCL_MAX_NCHANNELS (e.g. 4 .. 8) caps how many",
+    }
+
+
+def choose_gather(raybuffer_bytes, image_bytes):
+    """--gather auto: the gather that puts fewer bytes on the wire (the image gather pays a per-rank Phase 2 for it; BASELINE.json's north_star names the raybuffer gather)."""
+    pick = "image" if image_bytes < raybuffer_bytes else "raybuffer"
+    return {"gather": pick, "raybuffer_bytes": int(raybuffer_bytes), "image_bytes": int(image_bytes),
+            "why": f"{pick} gather: {min(raybuffer_bytes, image_bytes) / max(1, max(raybuffer_bytes, image_bytes)):.2f} x the bytes of the other (rank 0's share of step 0)"}
 
 
 def predict_frames_auto(frame_for, W, H, rank, N, budget_bytes, candidates=(512, 256, 128, 64, 32, 16, 8)):

@@ -348,3 +348,22 @@ def test_eight_rank_plan_of_the_4k_shapes_fits_its_hbm_budget(name, dim, lod_err
         for r in (0, N - 1):
             native = gpu.NativeShardPlan(ctx_free_pack, W, H, r, N)
             assert native.tile_count == plans[r].tile_count and list(native.send_start) == list(plans[r].send_start) and list(native.disp_start) == list(plans[r].disp_start)
+
+
+def test_multi_gpu_line_explains_itself():
+    """the N > 1 bench line carries the step's render alone, its exchange alone, what the overlap hid and what the payload takes on one
+    xGMI link (bench.scaling_breakdown); --gather auto takes the gather with fewer bytes (bench.choose_gather).  Host arithmetic: checked here, on
+    numbers of the shape an 8-GPU run will produce (render 22 ms, exchange 20 ms, 6.9 GB per GPU and step)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_module_breakdown", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    b = bench.scaling_breakdown(24.0, 22.0, 20.0, 6.9e9, 8)
+    assert b["render_ms_alone"] == 22.0 and b["exchange_ms_alone"] == 20.0
+    assert abs(b["overlap_efficiency"] - 0.9) < 1e-9          # 18 of the exchange's 20 ms hidden behind the render
+    assert abs(b["payload_ms_per_link_predicted"] - 6.9e9 / 7 / 153e9 * 1e3) < 1e-3
+    assert abs(b["exchange_effective_gbps_per_link"] - 6.9e9 / 7 / 20e-3 / 1e9) < 0.01
+    assert bench.scaling_breakdown(42.0, 22.0, 20.0, 1e9, 2)["overlap_efficiency"] == 0.0   # serialised
+    assert bench.scaling_breakdown(22.0, 22.0, 20.0, 1e9, 2)["overlap_efficiency"] == 1.0   # entirely hidden
+    assert bench.choose_gather(44e6, 33e6)["gather"] == "image" and bench.choose_gather(30e6, 33e6)["gather"] == "raybuffer"

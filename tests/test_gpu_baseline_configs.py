@@ -242,6 +242,28 @@ def test_downsample_refuses_a_non_lod0_source():
         ctx.close()
 
 
+def test_two_rank_rehearsal_line_carries_the_scaling_breakdown():
+    """The N > 1 path of bench.py as the driver starts it (`python bench.py --gpus 2`), rehearsed on ONE GPU with gloo: the line must verify its exchange
+    and explain itself -- render alone, exchange alone, overlap efficiency, predicted per-link payload time -- and `--gather auto`
+    must name the gather it took and the bytes of both."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--frames", "4", "--steps", "2", "--warmup", "1", "--gather", "auto"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["config"]["exchange_verified"] is True and line["config"]["ranks_seen"] == [0, 1]
+    for key in ("render_ms_alone", "exchange_ms_alone", "overlap_efficiency", "payload_ms_per_link_predicted", "exchange_effective_gbps_per_link"):
+        assert isinstance(line[key], float) and line[key] >= 0.0, key
+    auto = line["config"]["gather_auto"]
+    assert line["config"]["gather"] == auto["gather"] and auto["gather"] == ("image" if auto["image_bytes"] < auto["raybuffer_bytes"] else "raybuffer")
+
+
 def test_library_owned_rccl_communicator_single_rank():
     """cvx_comm_unique_id / cvx_comm_create / cvx_exchange / cvx_comm_destroy with one rank (all a one-GPU box can run): librccl
     is found and initialised by the library, and the exchange of a one-rank plan is a no-op that leaves the display area alone."""
