@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--check", type=int, default=16)
     ap.add_argument("--oracle", type=int, default=2)
     ap.add_argument("--frames-per-launch", default="")
+    ap.add_argument("--pose-range", default=None, help="lo:hi -- only benchmark-path samples lo <= i < hi (0:450 = one clamped top / bottom segment per frame, the shape of BASELINE config 5)")
     args = ap.parse_args()
 
     import numpy as np
@@ -47,6 +48,9 @@ def main():
 
     def frame_for(g):
         i = (g * 37) % 1000
+        if args.pose_range:
+            lo, hi = (int(v) for v in args.pose_range.split(":"))
+            i = lo + i % (hi - lo)
         pos, eul = host.sample_benchmark_path(i / 1000 * host.BENCHMARK_PATH_LENGTH, dims)
         return host.setup_frame(host.camera_pose(pos, eul, W, H), lods, far, W, H, dims[1])
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Everything profiles/rNN_* is made from, in one go on the GPU box: tools/profile_round.sh <tag, e.g. r02>
 # (kernel trace + stats, PMC passes, SQ stall / instruction counters of the default bench command; results under gpurun_out/<tag>/)
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
@@ -37,3 +37,10 @@ rm -rf "$OUT/trace" "$OUT"/pmc*/pass*/runc "$OUT"/pmc*/pass*/*/*agent_info.csv 2
 ls -la "$OUT"
 cat "$OUT/kernel_stats.csv" | head -8
 cat "$OUT/pmc_render_kernel.csv"
+# 6. single-frame latency (the reference's call pattern): kernel trace of 50 blocking draws + the SQ counters of the latency kernel
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_latency" -- python3 "$R/tools/single_frames.py" 200 > "$OUT/trace_latency.log" 2>&1
+find "$OUT/trace_latency" -name "*kernel_stats.csv" -exec cp {} "$OUT/kernel_stats_single_frames.csv" \;
+rm -rf "$OUT/trace_latency"
+bash "$R/tools/pmc_latency.sh" libcpuvox_gpu.so 50 > "$OUT/sq_counters_single_frames.txt" 2>&1
+cat "$OUT/kernel_stats_single_frames.csv" | head -5
