@@ -896,7 +896,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 // ---------------------------------------------------------------------------
 template <bool HI>
 #ifndef CVX_LONE_WAVES_PER_SIMD
-#define CVX_LONE_WAVES_PER_SIMD 2
+#define CVX_LONE_WAVES_PER_SIMD 3
 #endif
 __global__ __launch_bounds__(CVX_WAVE, CVX_LONE_WAVES_PER_SIMD) void lone_kernel(const DevFrame *__restrict__ frames, const DevTile *__restrict__ tiles, const DevWorld *__restrict__ world)
 {
