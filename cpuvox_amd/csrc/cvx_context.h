@@ -51,6 +51,7 @@ struct cvx_context {
 		bool pending = false;           // host vectors hold data that is not in the arena yet
 		int rowShift = 0;
 		int colorShift = 7;             // log2 of the bytes between two colours of a column (cvx_device.h)
+		int64_t solidColumns = 0, listedColumns = 0; // non-empty columns of the level, and how many of them keep their runs in the run list (code 0)
 	};
 	HostLevel hostLevel[CVX_LOD_LEVELS];
 	uint8_t *arena = nullptr;

@@ -174,6 +174,7 @@ int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byt
 	H.colorShift = blocked ? 7 : 2; // log2 of the bytes between two colours of a column
 	size_t denseCursor = CVX_COLOR_STRIDE;
 	size_t listCursor = 0;
+	H.solidColumns = H.listedColumns = 0;
 	for (int64_t cx = 0; cx < usedX; cx++) {
 		for (int64_t cz = 0; cz < usedZ; cz++) {
 			const int64_t i = cx * usedZ + cz; // World.GetIndexKnownInBounds, World.cs:145-149
@@ -195,7 +196,9 @@ int cvx_world_upload(cvx_context *ctx, int lod, const void *storage, int64_t byt
 			denseCursor += colourCounts[(size_t)i];
 			const uint32_t bounds = (uint32_t)h.worldMin | ((uint32_t)h.worldMax << 16);
 			uint32_t z = 0, w = 0;
+			H.solidColumns++;
 			if (code == 0u) {
+				H.listedColumns++;
 				const size_t block = listCursor;
 				uint32_t start = 0;
 				for (int r = 0; r < n; r++) { // top-down
