@@ -763,10 +763,7 @@ int DrawBatch(cvx_context *ctx, int frameCount, const cvx_segment_data *segments
 		// A launch of few rays (the reference's call pattern: ONE frame per blocking call, RenderManager.cs:358-363) goes to the latency kernel
 		// (cvx_lone.h): one wave per RAY, its lanes the ray's next 64 columns.  Its mask lives in one or two vector registers: windows of up to 4096 pixels.
 		ctx->launchLone = 0;
-		// (AUTO: not for worlds whose columns largely live in the run list -- model worlds with many thin runs per column, foreign blobs: the latency kernel
-		// takes such a column apart run by run with wave-uniform operands, and the batch kernel is as fast or faster there: mill.obj at 512^3, 1080p: 2.31 against 2.53 ms)
-		const bool listedWorld = ctx->hostLevel[0].listedColumns * 50 > ctx->hostLevel[0].solidColumns; // more than 2 % of LOD 0's columns
-		if (!ctx->countersEnabled && ctx->maskWordsNeeded <= 2 * CVX_WAVE && (ctx->loneMode == 2 || (ctx->loneMode == 1 && !listedWorld && n * (size_t)CVX_WAVE <= (size_t)ctx->loneWaveBudget)) && n > 0) {
+		if (!ctx->countersEnabled && ctx->maskWordsNeeded <= 2 * CVX_WAVE && (ctx->loneMode == 2 || (ctx->loneMode == 1 && n * (size_t)CVX_WAVE <= (size_t)ctx->loneWaveBudget)) && n > 0) {
 			// (one workgroup per RAY: the kernel takes tile blockIdx / 64, ray blockIdx % 64 of it -- the tile list goes to the device as it is, longest tiles first)
 			std::vector<DevTile> sortedTiles;
 			sortedTiles.reserve(n);

@@ -595,6 +595,27 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 			}
 		};
 
+		// Can a pixel range change the ray's state?  It has to overlap the window [nextFreePixelMin, Max] (:505 / :581) -- and to hold an UNSEEN pixel:
+		// ReducePixelHorizon (:660-697) moves a bound only when the range covers it (and the bounds are unseen pixels), the pixel loops only write unseen
+		// pixels.  More than two thirds of the overlapping runs of the benchmark world hold none (the far side of a floating slab whose near side is drawn).
+		// Per lane (a column's run in runTests, a run of the run list in processColumn): the mask word of the first pixel of the clamped range [lo, hi] comes
+		// from the lane that holds it (ds_bpermute); a range that goes on into a second word counts as writable (the run's turn makes the exact tests).
+		auto windowIsClean = [&]() -> bool { // no seen pixel inside the window: every overlapping range is writable (one ballot instead of a gather per range)
+			bool clean = __ballot((seen.w0 & range_mask_any(seen.wordBase + lane, nextFreePixelMin, nextFreePixelMax)) != 0u) == 0ull;
+			if (HI) { clean = clean && __ballot((seen.w1 & range_mask_any(seen.wordBase + 64 + lane, nextFreePixelMin, nextFreePixelMax)) != 0u) == 0ull; }
+			return clean;
+		};
+		auto mayHoldUnseen = [&](int lo, int hi) -> bool {
+			const int i = (lo >> 5) - seen.wordBase, first = lo & 31;
+			uint32_t word = (uint32_t)__builtin_amdgcn_ds_bpermute((i & 63) << 2, (int)seen.w0);
+			if (HI) {
+				const uint32_t word1 = (uint32_t)__builtin_amdgcn_ds_bpermute((i & 63) << 2, (int)seen.w1);
+				word = i < CVX_WAVE ? word : word1;
+			}
+			const int more = min(hi - lo, 31 - first); // pixels of the range in this word, less one
+			return ((int)((hi - lo) > more) | (int)(((~word >> first) << (31 - more)) != 0u)) != 0;
+		};
+
 		// ---- element loop (:424-611) of column j, run by run in the reference's walk order, with the ray's current state
 		auto processColumn = [&](int j) {
 			CVX_LSTAT(9);
@@ -609,26 +630,59 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 			const uint32_t bits = rlu(todo, j);
 			if (CVX_RARE((bits & 0x80000000u) != 0u)) {
 				CVX_LSTAT(10);
+				// A column of the run list (cvx_device.h: a few per thousand of a built terrain, most columns of a model world such as mill.obj -- ten thin runs
+				// and more per column --, every column of a foreign blob).  Here the lanes are the column's RUNS, 64 at a time in the reference's walk order
+				// (:428-437): one load brings them all, one pass projects them all (project_run with the column's corners, wave-uniform, and a run per lane),
+				// one more fetches their face colours; then the runs that can touch the state take their turn one after the other (drawRun with the lane's values).
 				const float worldBoundsMin = rlf(wbMin, j), worldBoundsMax = rlf(wbMax, j);
-				const uint32_t columnColorsOff = rlu(colorsOff, j);
-				// a column of the run list (cvx_device.h: a few per thousand of a built world, every column of a foreign blob): its runs are fetched and
-				// projected when their turn comes, with wave-uniform operands
+				const uint32_t columnColorsOff = L.elementsOff + (rlu(rec.x, j) & 0x3FFFFFFFu) * 4u;
 				const uint32_t columnRunsOff = L.runsOff + rlu(rec.z, j) * 8u;
 				const int solidCount = (int)rlu(rec.w, j);
-				const f3 qMinLast = f3{ rlf(camSpaceMinLast.x, j), rlf(camSpaceMinLast.y, j), rlf(camSpaceMinLast.z, j) };
-				const f3 qMaxLast = f3{ rlf(camSpaceMaxLast.x, j), rlf(camSpaceMaxLast.y, j), rlf(camSpaceMaxLast.z, j) };
-				const f3 qMinNext = f3{ rlf(camSpaceMinNext.x, j), rlf(camSpaceMinNext.y, j), rlf(camSpaceMinNext.z, j) };
-				const f3 qMaxNext = f3{ rlf(camSpaceMaxNext.x, j), rlf(camSpaceMaxNext.y, j), rlf(camSpaceMaxNext.z, j) };
-				for (int k = 0; k < solidCount && alive; k++) {
-					const uint2 run = ld2(arena, columnRunsOff + (uint32_t)(DIR > 0 ? k : solidCount - 1 - k) * 8u);
+				const float dL = rlf(wDistLast, j), dN = rlf(wDistNext, j); // :289-293 again, from the column's two distances
+				const f3 qMinLast = f3_madd(planeStartBottom, planeDir, dL), qMinNext = f3_madd(planeStartBottom, planeDir, dN);
+				const f3 qMaxLast = f3_madd(planeStartTop, planeDir, dL), qMaxNext = f3_madd(planeStartTop, planeDir, dN);
+				for (int first = 0; first < solidCount && alive; first += CVX_WAVE) {
+					const int position = first + lane; // in walk order
+					const bool have = position < solidCount;
+					uint2 run = uint2{ 0u, 0u };
+					if (have) { run = ld2(arena, columnRunsOff + (uint32_t)(DIR > 0 ? position : solidCount - 1 - position) * 8u); }
 					const float elementBoundsMin = (float)(run.x & 0xFFFFu), elementBoundsMax = (float)(run.x >> 16) + 1.0f;
-					if (elementBoundsMin > worldBoundsMax || elementBoundsMax < worldBoundsMin) { continue; } // :461-475
 					const int elementLength = (int)(((run.x >> 16) + 1u - (run.x & 0xFFFFu)) >> lod);
 					const int elementColorsIndex = (int)(run.y & 0xFFFFu);
-					RunProj R = project_run(qMinLast, qMaxLast, qMinNext, qMaxNext, elementBoundsMin, elementBoundsMax, elementLength, cameraPosYNormalized, invWorldMaxY);
-					R.rbMinS = uni(R.rbMinS); R.rbMaxS = uni(R.rbMaxS); R.rbMinF = uni(R.rbMinF); R.rbMaxF = uni(R.rbMaxF); // (f2i is inline asm: see uni())
-					const uint32_t secondaryColor = ld_color(arena, columnColorsOff + ((uint32_t)(R.faceTop ? elementColorsIndex : elementColorsIndex + elementLength - 1) << L.colorShift));
-					drawRun(R, elementBoundsMin, elementBoundsMax, elementLength, elementColorsIndex, columnColorsOff, secondaryColor, worldBoundsMin, worldBoundsMax);
+					const bool in = ((int)have & (int)!(elementBoundsMin > worldBoundsMax) & (int)!(elementBoundsMax < worldBoundsMin)) != 0; // :461-475
+					const RunProj R = project_run(qMinLast, qMaxLast, qMinNext, qMaxNext, elementBoundsMin, elementBoundsMax, elementLength, cameraPosYNormalized, invWorldMaxY);
+					uint32_t secondaryColor = 0u;
+					if (in) { secondaryColor = ld_color(arena, columnColorsOff + ((uint32_t)(R.faceTop ? elementColorsIndex : elementColorsIndex + elementLength - 1) << L.colorShift)); }
+					const int loS = max(R.rbMinS, nextFreePixelMin), hiS = min(R.rbMaxS, nextFreePixelMax), loF = max(R.rbMinF, nextFreePixelMin), hiF = min(R.rbMaxF, nextFreePixelMax);
+					const bool side = ((int)in & (int)R.sideVisible & (int)(loS <= hiS)) != 0;
+					const bool wanted = (((int)R.faceTop & (int)!(elementBoundsMax > worldBoundsMax)) | ((int)R.faceBottom & (int)!(elementBoundsMin < worldBoundsMin))) != 0;
+					const bool face = ((int)in & (int)wanted & (int)R.faceNear & (int)(loF <= hiF)) != 0;
+					const uint32_t runFlags = (R.sideVisible ? 1u : 0u) | (R.faceNear ? 2u : 0u) | (R.faceTop ? 4u : 0u) | (R.faceBottom ? 8u : 0u);
+					bool writable = true;
+					if (!windowIsClean()) { writable = mayHoldUnseen(side ? (face ? min(loS, loF) : loS) : loF, side ? (face ? max(hiS, hiF) : hiS) : hiF); }
+					lanemask_t candidates = __ballot((side || face) && writable);
+					while (candidates != 0ull && alive) {
+						const int l = __ffsll((long long)candidates) - 1;
+						candidates &= candidates - 1ull;
+						RunProj U;
+						const uint32_t uf = rlu(runFlags, l);
+						U.sideVisible = (uf & 1u) != 0u;
+						U.faceNear = (uf & 2u) != 0u;
+						U.faceTop = (uf & 4u) != 0u;
+						U.faceBottom = (uf & 8u) != 0u;
+						U.rbMinS = rli(R.rbMinS, l);
+						U.rbMaxS = rli(R.rbMaxS, l);
+						U.rbMinF = rli(R.rbMinF, l);
+						U.rbMaxF = rli(R.rbMaxF, l);
+						U.boundsX = rlf(R.boundsX, l);
+						U.boundsY = rlf(R.boundsY, l);
+						U.uvAx = rlf(R.uvAx, l);
+						U.uvBx = rlf(R.uvBx, l);
+						U.uvAy = rlf(R.uvAy, l);
+						U.uvBy = rlf(R.uvBy, l);
+						drawRun(U, rlf(elementBoundsMin, l), rlf(elementBoundsMax, l), rli(elementLength, l), rli(elementColorsIndex, l), columnColorsOff, rlu(secondaryColor, l), worldBoundsMin,
+						        worldBoundsMax);
+					}
 				}
 				return;
 			}
@@ -766,15 +820,11 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 		// of run r, bit 2r + 1 = its face, bit 31 = a column of the run list (looked at when its turn comes)
 		// which runs of the lane's column can touch the ray's state, given the column's world bounds (wbMin / wbMax) and the current window: bit 2r = the side
 		// of run r, bit 2r + 1 = its face, bit 31 = a column of the run list (looked at when its turn comes).
-		// A run's side / face has to overlap the window [nextFreePixelMin, Max] (:505 / :581) -- and to hold an UNSEEN pixel: ReducePixelHorizon (:660-697) moves
-		// a bound only when the range covers it (and the bounds are unseen pixels), the pixel loops only write unseen pixels.  More than two thirds of the
-		// overlapping runs of the benchmark world hold none (the far side of a floating slab whose near side is drawn).  So, unless the window holds no seen
-		// pixel at all (one ballot), the mask word of the first pixel of the run's clamped range (side and face together) comes from the lane that holds it
-		// (ds_bpermute); a range that goes on into a second word counts as writable (the column's turn in processColumn makes the exact tests either way).
+		// A run's side / face has to overlap the window (:505 / :581) and to hold an unseen pixel (windowIsClean / mayHoldUnseen above: one test for the run's
+		// side and face together).
 		auto runTests = [&]() {
 			todo = (flags & CVX_LF_LISTED) != 0u ? 0x80000000u : 0u;
-			bool windowClean = __ballot((seen.w0 & range_mask_any(seen.wordBase + lane, nextFreePixelMin, nextFreePixelMax)) != 0u) == 0ull;
-			if (HI) { windowClean = windowClean && __ballot((seen.w1 & range_mask_any(seen.wordBase + 64 + lane, nextFreePixelMin, nextFreePixelMax)) != 0u) == 0ull; }
+			const bool windowClean = windowIsClean();
 #pragma unroll
 			for (int r = 0; r < 3; r++) {
 				if (r > 0 && !anyRun[r]) { continue; } // (wave-uniform: no column of the window has such a run)
@@ -786,17 +836,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 				const bool wanted = (((int)((f & CVX_LF_FACETOP) != 0u) & (int)!(t > wbMax)) | ((int)((f & CVX_LF_FACEBOTTOM) != 0u) & (int)!(b < wbMin))) != 0; // :549-565
 				const bool face = ((int)in & (int)wanted & (int)((f & CVX_LF_FACENEAR) != 0u) & (int)(loF <= hiF)) != 0;                                         // :581
 				bool writable = true;
-				if (!windowClean) {
-					const int lo = side ? (face ? min(loS, loF) : loS) : loF, hi = side ? (face ? max(hiS, hiF) : hiS) : hiF;
-					const int i = (lo >> 5) - seen.wordBase, first = lo & 31;
-					uint32_t word = (uint32_t)__builtin_amdgcn_ds_bpermute((i & 63) << 2, (int)seen.w0);
-					if (HI) {
-						const uint32_t word1 = (uint32_t)__builtin_amdgcn_ds_bpermute((i & 63) << 2, (int)seen.w1);
-						word = i < CVX_WAVE ? word : word1;
-					}
-					const int more = min(hi - lo, 31 - first); // pixels of the range in this word, less one
-					writable = ((int)((hi - lo) > more) | (int)(((~word >> first) << (31 - more)) != 0u)) != 0;
-				}
+				if (!windowClean) { writable = mayHoldUnseen(side ? (face ? min(loS, loF) : loS) : loF, side ? (face ? max(hiS, hiF) : hiS) : hiF); }
 				todo |= ((int)side & (int)writable ? 1u << (2 * r) : 0u) | ((int)face & (int)writable ? 2u << (2 * r) : 0u);
 			}
 		};
