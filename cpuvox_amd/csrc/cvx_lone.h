@@ -540,8 +540,10 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 					int row = tex_row_cheap(y, boundsX, uvAx, uvAy, texRun, certain);
 					if (CVX_RARE(!certain)) { row = tex_row_exact(y, boundsX, boundsY, uvAx, uvBx, uvAy, uvBy); }
 					const int colorIdx = m_clampi(row, 0, elementLength - 1) + elementColorsIndex;
-					const uint32_t c = ld_color(arena, columnColorsOff + ((uint32_t)colorIdx << L.colorShift));
-					pix[y] = c;
+					// the colour goes from memory STRAIGHT into the ray's row in LDS (global_load_lds_dword: lane p's dword lands at the LDS base + 4 p, and lane
+					// p IS pixel yb + p): no register, so nothing waits for the load until the row is read out at the end of the ray
+					__builtin_amdgcn_global_load_lds((const CVX_GLOBAL uint32_t *)(arena + (columnColorsOff + ((uint32_t)colorIdx << L.colorShift))),
+					                                 (__attribute__((address_space(3))) uint32_t *)(pix + yb), 4, 0, 0);
 				}
 			}
 			lone_mark<HI>(seen, rbMin, rbMax);
@@ -993,7 +995,9 @@ __global__ __launch_bounds__(CVX_WAVE, CVX_LONE_WAVES_PER_SIMD) void lone_kernel
 		}
 	}
 #endif
-	// the row goes out: pixel y of this ray at tile row y (256 bytes per row, cvx_device.h)
+	// the row goes out: pixel y of this ray at tile row y (256 bytes per row, cvx_device.h); first every colour still on its way into the row has to be there
+	__builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0) (gfx9 encoding, see cvx_kernels.h)
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 	CVX_LSEC(11);
 	for (int y = omin + seen.lane; y <= omax; y += CVX_WAVE) { st_pixel(tileOut, laneByteOff, y, pix[y]); }
 }
