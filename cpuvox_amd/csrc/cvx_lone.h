@@ -52,10 +52,16 @@ __device__ unsigned long long g_loneLongest[48];
 #else
 #define CVX_LSEC(n) ((void)0)
 #endif
+#if defined(CVX_LONE_TIMES) && CVX_LONE_TIMES >= 2 /* ... stamps inside the events too (they cost as much as what they measure: shares only) */
+#define CVX_LSECE(n) CVX_LSEC(n)
+#else
+#define CVX_LSECE(n) ((void)0)
+#endif
 #else
 #define CVX_LSTAT(n) ((void)0)
 #define CVX_LSTAT_ADD(n, v) ((void)0)
 #define CVX_LSEC(n) ((void)0)
+#define CVX_LSECE(n) ((void)0)
 #endif
 
 __device__ __forceinline__ float rlf(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
@@ -472,6 +478,11 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 			const int px = wPos >> 16, pz = wPos & 0xFFFF;
 			rec = ld4(arena, L.recordsOff + record_offset(px >> L.shift, pz >> L.shift, L.rowShift));
 		}
+#ifdef CVX_LONE_TIMES /* how long the wave waits for the window's records (diagnostic build only) */
+		CVX_LSEC(12);
+		__builtin_amdgcn_s_waitcnt(0x0F70);
+		CVX_LSEC(2);
+#endif
 		// :289-293 (per lane)
 		const f3 camSpaceMinLast = f3_madd(planeStartBottom, planeDir, wDistLast);
 		const f3 camSpaceMinNext = f3_madd(planeStartBottom, planeDir, wDistNext);
@@ -569,14 +580,14 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 				if (rbMax >= nextFreePixelMin && rbMin <= nextFreePixelMax) { // :505
 					CVX_LSTAT(7);
 					CVX_LMARK("sidereduce_begin");
-					CVX_LSEC(7);
+					CVX_LSECE(7);
 					lone_reduce_pixel_horizon<HI>(seen, omin, omax, rbMin, rbMax, nextFreePixelMin, nextFreePixelMax, frustumBoundsMin, frustumBoundsMax);
 					CVX_LMARK("sidereduce_end");
-					CVX_LSEC(8);
+					CVX_LSECE(8);
 					if (rbMin <= rbMax) { sidePixels(rbMin, rbMax, R.boundsX, R.boundsY, R.uvAx, R.uvBx, R.uvAy, R.uvBy, elementLength, elementColorsIndex, columnColorsOff); }
 					if (nextFreePixelMin > nextFreePixelMax) { alive = false; return; } // :535-539
 					CVX_LMARK("sidepixels_end");
-					CVX_LSEC(6);
+					CVX_LSECE(6);
 				}
 			}
 			const bool faceWanted = (R.faceTop && !(elementBoundsMax > worldBoundsMax)) || (R.faceBottom && !(elementBoundsMin < worldBoundsMin)); // :549-565
@@ -585,14 +596,14 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 				if (rbMax >= nextFreePixelMin && rbMin <= nextFreePixelMax) { // :581
 					CVX_LSTAT(8);
 					CVX_LMARK("facereduce_begin");
-					CVX_LSEC(9);
+					CVX_LSECE(9);
 					lone_reduce_pixel_horizon<HI>(seen, omin, omax, rbMin, rbMax, nextFreePixelMin, nextFreePixelMax, frustumBoundsMin, frustumBoundsMax);
 					CVX_LMARK("facereduce_end");
-					CVX_LSEC(10);
+					CVX_LSECE(10);
 					if (rbMin <= rbMax) { facePixels(rbMin, rbMax, secondaryColor); }
 					if (nextFreePixelMin > nextFreePixelMax) { alive = false; return; } // :604-608
 					CVX_LMARK("facepixels_end");
-					CVX_LSEC(6);
+					CVX_LSECE(6);
 				}
 			}
 		};
@@ -622,7 +633,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 		auto processColumn = [&](int j) {
 			CVX_LSTAT(9);
 			CVX_LMARK("process_begin");
-			CVX_LSEC(6);
+			CVX_LSECE(6);
 #ifdef CVX_LONE_STATS
 			{ // how often the window [nextFreePixelMin, Max] holds no seen pixel when a column is processed ("clean": every scan / unseen test is then trivial)
 				int n_ = __popc(seen.w0 & range_mask_any(seen.wordBase + lane, nextFreePixelMin, nextFreePixelMax)) + (HI ? __popc(seen.w1 & range_mask_any(seen.wordBase + 64 + lane, nextFreePixelMin, nextFreePixelMax)) : 0);
@@ -699,17 +710,17 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 					if (rbMax >= nextFreePixelMin && rbMin <= nextFreePixelMax) { // :505
 						CVX_LSTAT(7);
 						CVX_LMARK("sidereduce_begin");
-						CVX_LSEC(7);
+						CVX_LSECE(7);
 						lone_reduce_pixel_horizon<HI>(seen, omin, omax, rbMin, rbMax, nextFreePixelMin, nextFreePixelMax, frustumBoundsMin, frustumBoundsMax);
 						CVX_LMARK("sidereduce_end");
-						CVX_LSEC(8);
+						CVX_LSECE(8);
 						if (rbMin <= rbMax) {
 							sidePixels(rbMin, rbMax, rlf(P[r].boundsX, j), rlf(P[r].boundsY, j), rlf(P[r].uvAx, j), rlf(P[r].uvBx, j), rlf(P[r].uvAy, j), rlf(P[r].uvBy, j), rli(runLen[r], j), rli(runCidx[r], j),
 							           rlu(colorsOff, j));
 						}
 						if (nextFreePixelMin > nextFreePixelMax) { alive = false; return; } // :535-539
 						CVX_LMARK("sidepixels_end");
-						CVX_LSEC(6);
+						CVX_LSECE(6);
 					}
 				}
 				if ((bits & (2u << (2 * r))) != 0u) {
@@ -717,14 +728,14 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 					if (rbMax >= nextFreePixelMin && rbMin <= nextFreePixelMax) { // :581
 						CVX_LSTAT(8);
 						CVX_LMARK("facereduce_begin");
-						CVX_LSEC(9);
+						CVX_LSECE(9);
 						lone_reduce_pixel_horizon<HI>(seen, omin, omax, rbMin, rbMax, nextFreePixelMin, nextFreePixelMax, frustumBoundsMin, frustumBoundsMax);
 						CVX_LMARK("facereduce_end");
-						CVX_LSEC(10);
+						CVX_LSECE(10);
 						if (rbMin <= rbMax) { facePixels(rbMin, rbMax, rlu(faceColor[r], j)); }
 						if (nextFreePixelMin > nextFreePixelMax) { alive = false; return; } // :604-608
 						CVX_LMARK("facepixels_end");
-						CVX_LSEC(6);
+						CVX_LSECE(6);
 					}
 				}
 			}
@@ -742,7 +753,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 		auto clipColumn = [&](int j) {
 			CVX_LSTAT(11);
 			CVX_LMARK("clip_begin");
-			CVX_LSEC(3);
+			CVX_LSECE(3);
 			const float dL = rlf(wDistLast, j), dN = rlf(wDistNext, j);
 			const float dist = roleNext ? dN : dL;
 			// :289-293 for this lane's intersection (x and z: the clip never looks at y)
@@ -792,7 +803,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 			CVX_LMARK("clip_end");
 			if (!CVX_USUAL(windowUntouched)) {
 				CVX_LSTAT(13);
-				CVX_LSEC(4);
+				CVX_LSECE(4);
 				const float mine = ptX / ptZ; // lanes: minLast, maxLast, minNext, maxNext
 				const float partner = quadSwapMax(mine);
 				const bool sw = roleMax ? mine < partner : partner < mine; // :339-346: max < min -> swap
@@ -846,7 +857,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 		auto cullAndFilter = [&](int from, int clipped) {
 			CVX_LSTAT(14);
 			CVX_LMARK("filter_begin");
-			CVX_LSEC(5);
+			CVX_LSECE(5);
 			const float columnWorldMin = (float)(rec.y & 0xFFFFu);
 			const float columnWorldMax = (float)(rec.y >> 16);
 			const float newMax = posY + hw_max(frustumDirMaxWorld * wDistNext, frustumDirMaxWorld * wDistLast);
@@ -862,10 +873,15 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 			hits = __ballot(draw && todo != 0u) & range;
 			leftWorldMask = __ballot(leftWorld) & range;
 			CVX_LMARK("filter_end");
-			CVX_LSEC(0);
+			CVX_LSECE(0);
 		};
 
 		CVX_LSEC(0);
+#ifdef CVX_LONE_TIMES /* ... and for the face colours */
+		CVX_LSEC(13);
+		__builtin_amdgcn_s_waitcnt(0x0F70);
+		CVX_LSEC(0);
+#endif
 		// ---- the events of the window, in column order
 		int next = 0;         // first lane not yet looked at
 		bool hitsValid = false;
@@ -877,7 +893,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 				const int j = __ffsll((long long)rem) - 1;
 				if (rlf(wDistLast, j) > 2.0f) {
 					clipColumn(j);
-					CVX_LSEC(0);
+					CVX_LSECE(0);
 					if (!alive) { break; }
 					cullAndFilter(j, j);
 					hitsValid = true;
@@ -885,7 +901,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 					if ((hits >> j) & 1ull) {
 						CVX_LSTAT(21);
 						processColumn(j);
-						CVX_LSEC(0);
+						CVX_LSECE(0);
 						if (frustumDirMaxWorld == CVX_FLOAT_EPSILON) { hitsValid = false; }
 					}
 					next = j + 1;
@@ -893,7 +909,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 					{ const bool mine = lane == j; wbMin = mine ? 0.0f : wbMin; wbMax = mine ? worldMaxY : wbMax; }
 					runTests();
 					processColumn(j);
-					CVX_LSEC(0);
+					CVX_LSECE(0);
 					next = j + 1;
 					hitsValid = false;
 				}
@@ -909,7 +925,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 				const int fh = h != 0ull ? __ffsll((long long)h) - 1 : CVX_WAVE, fl = l != 0ull ? __ffsll((long long)l) - 1 : CVX_WAVE;
 				if (fl < fh) { alive = false; break; } // :265-269: the frustum left the world
 				processColumn(fh);
-				CVX_LSEC(0);
+				CVX_LSECE(0);
 				next = fh + 1;
 				if (frustumDirMaxWorld == CVX_FLOAT_EPSILON) { hitsValid = false; } // a pixel was written: the directions are gone (:522,598)
 			}

@@ -1,7 +1,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/icache
 rm -rf $OUT; mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
-timeout 200 rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_WAVE_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $OUT/p1 -- python3 $R/tools/single_frames.py 50 > $OUT/p1.log 2>&1
+timeout 200 rocprofv3 --pmc ${CVX_PMC:-SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_WAVE_CYCLES SQ_WAIT_INST_ANY} --output-format csv -d $OUT/p1 -- python3 $R/tools/single_frames.py 50 > $OUT/p1.log 2>&1
 python3 - $OUT <<'PY'
 import csv, glob, sys
 from collections import defaultdict

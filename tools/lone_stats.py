@@ -49,7 +49,7 @@ print(f"per frame ({poses} frames {W}x{H} {world}):")
 for i, n in enumerate(names):
     print(f"  {n:50s} {out[i] / poses:12.1f}     longest wave: {longest[i] / poses:10.1f}")
 sections = ["event loop / other", "window: DDA", "window: records + projections", "clip", "clip: window touched", "cull + filter", "column glue", "side: horizon", "side: pixels",
-            "face: horizon", "face: pixels", "skybox pass"]
+            "face: horizon", "face: pixels", "skybox pass", "window: waiting for the records", "window: waiting for the face colours"]
 total = sum(out[32 + i] for i in range(len(sections)))
 if total:
     print("share of wave cycles per section (s_memtime, -DCVX_LONE_TIMES):")
