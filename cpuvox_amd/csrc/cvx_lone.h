@@ -102,8 +102,8 @@ __device__ __forceinline__ uint32_t lone_word(const LoneSeen &s, int i)
 template <bool HI>
 __device__ __forceinline__ int lone_scan_up(const LoneSeen &s, int start, int omax)
 {
-	if (start > omax) { return start; }
-	if (((lone_word<HI>(s, (start >> 5) - s.wordBase) >> (start & 31)) & 1u) == 0u) { return start; } // (the usual case: the pixel right above the run is unseen)
+	if (CVX_RARE(start > omax)) { return start; }
+	if (CVX_USUAL(((lone_word<HI>(s, (start >> 5) - s.wordBase) >> (start & 31)) & 1u) == 0u)) { return start; } // (the usual case: the pixel right above the run is unseen)
 	const uint32_t m0 = ~s.w0 & range_mask_any(s.wordBase + s.lane, start, omax);
 	const lanemask_t b0 = __ballot(m0 != 0u);
 	if (b0 != 0ull) {
@@ -125,8 +125,8 @@ __device__ __forceinline__ int lone_scan_up(const LoneSeen &s, int start, int om
 template <bool HI>
 __device__ __forceinline__ int lone_scan_down(const LoneSeen &s, int start, int omin)
 {
-	if (start < omin) { return start; }
-	if (((lone_word<HI>(s, (start >> 5) - s.wordBase) >> (start & 31)) & 1u) == 0u) { return start; } // (the usual case: the pixel right below the run is unseen)
+	if (CVX_RARE(start < omin)) { return start; }
+	if (CVX_USUAL(((lone_word<HI>(s, (start >> 5) - s.wordBase) >> (start & 31)) & 1u) == 0u)) { return start; } // (the usual case: the pixel right below the run is unseen)
 	if (HI) {
 		const uint32_t m1 = ~s.w1 & range_mask_any(s.wordBase + 64 + s.lane, omin, start);
 		const lanemask_t b1 = __ballot(m1 != 0u);
@@ -178,7 +178,7 @@ template <bool HI>
 __device__ __forceinline__ lanemask_t lone_unseen(const LoneSeen &s, int yb, int n)
 {
 	const int sh = yb & 31;
-	if (sh + n <= 32) { return (lanemask_t)((~lone_word<HI>(s, (yb >> 5) - s.wordBase) >> sh) & (0xFFFFFFFFu >> (32 - n))); }
+	if (CVX_USUAL(sh + n <= 32)) { return (lanemask_t)((~lone_word<HI>(s, (yb >> 5) - s.wordBase) >> sh) & (0xFFFFFFFFu >> (32 - n))); }
 	return lone_unseen64<HI>(s, yb) & (n >= CVX_WAVE ? ~0ull : ((1ull << n) - 1ull));
 }
 
@@ -541,7 +541,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 			for (int yb = rbMin; yb <= rbMax; yb += CVX_WAVE) {
 				const int n = min(CVX_WAVE, rbMax - yb + 1);
 				const lanemask_t todo = lone_unseen<HI>(seen, yb, n);
-				if (todo == 0ull) { continue; }
+				if (CVX_RARE(todo == 0ull)) { continue; }
 				CVX_LSTAT(3);
 				CVX_LSTAT_ADD(4, __popcll(todo));
 				frustumDirMaxWorld = CVX_FLOAT_EPSILON; // :522
@@ -564,7 +564,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 			for (int yb = rbMin; yb <= rbMax; yb += CVX_WAVE) {
 				const int n = min(CVX_WAVE, rbMax - yb + 1);
 				const lanemask_t todo = lone_unseen<HI>(seen, yb, n);
-				if (todo == 0ull) { continue; }
+				if (CVX_RARE(todo == 0ull)) { continue; }
 				CVX_LSTAT(5);
 				CVX_LSTAT_ADD(6, __popcll(todo));
 				frustumDirMaxWorld = CVX_FLOAT_EPSILON; // :598
@@ -707,33 +707,33 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 				const int r = DIR > 0 ? rr : 2 - rr; // the walk starts at the top (ITERATION_DIRECTION +1) or at the bottom (-1), :428-437
 				if ((bits & (1u << (2 * r))) != 0u) {
 					int rbMin = rli(P[r].rbMinS, j), rbMax = rli(P[r].rbMaxS, j);
-					if (rbMax >= nextFreePixelMin && rbMin <= nextFreePixelMax) { // :505
+					if (CVX_USUAL(rbMax >= nextFreePixelMin && rbMin <= nextFreePixelMax)) { // :505
 						CVX_LSTAT(7);
 						CVX_LMARK("sidereduce_begin");
 						CVX_LSECE(7);
 						lone_reduce_pixel_horizon<HI>(seen, omin, omax, rbMin, rbMax, nextFreePixelMin, nextFreePixelMax, frustumBoundsMin, frustumBoundsMax);
 						CVX_LMARK("sidereduce_end");
 						CVX_LSECE(8);
-						if (rbMin <= rbMax) {
+						if (CVX_USUAL(rbMin <= rbMax)) {
 							sidePixels(rbMin, rbMax, rlf(P[r].boundsX, j), rlf(P[r].boundsY, j), rlf(P[r].uvAx, j), rlf(P[r].uvBx, j), rlf(P[r].uvAy, j), rlf(P[r].uvBy, j), rli(runLen[r], j), rli(runCidx[r], j),
 							           rlu(colorsOff, j));
 						}
-						if (nextFreePixelMin > nextFreePixelMax) { alive = false; return; } // :535-539
+						if (CVX_RARE(nextFreePixelMin > nextFreePixelMax)) { alive = false; return; } // :535-539
 						CVX_LMARK("sidepixels_end");
 						CVX_LSECE(6);
 					}
 				}
 				if ((bits & (2u << (2 * r))) != 0u) {
 					int rbMin = rli(P[r].rbMinF, j), rbMax = rli(P[r].rbMaxF, j);
-					if (rbMax >= nextFreePixelMin && rbMin <= nextFreePixelMax) { // :581
+					if (CVX_USUAL(rbMax >= nextFreePixelMin && rbMin <= nextFreePixelMax)) { // :581
 						CVX_LSTAT(8);
 						CVX_LMARK("facereduce_begin");
 						CVX_LSECE(9);
 						lone_reduce_pixel_horizon<HI>(seen, omin, omax, rbMin, rbMax, nextFreePixelMin, nextFreePixelMax, frustumBoundsMin, frustumBoundsMax);
 						CVX_LMARK("facereduce_end");
 						CVX_LSECE(10);
-						if (rbMin <= rbMax) { facePixels(rbMin, rbMax, rlu(faceColor[r], j)); }
-						if (nextFreePixelMin > nextFreePixelMax) { alive = false; return; } // :604-608
+						if (CVX_USUAL(rbMin <= rbMax)) { facePixels(rbMin, rbMax, rlu(faceColor[r], j)); }
+						if (CVX_RARE(nextFreePixelMin > nextFreePixelMax)) { alive = false; return; } // :604-608
 						CVX_LMARK("facepixels_end");
 						CVX_LSECE(6);
 					}
