@@ -157,6 +157,25 @@ def test_random_poses_fuzz_mill_and_odd_resolutions(contexts):
                 _compare(f"millfuzz {W}x{H} #{i} [{label}] pos={pos} eul={eul}", fr, g_td, g_lr, o_td, o_lr)
 
 
+def test_latency_kernel_wide_windows_fuzz(contexts):
+    """The latency kernel keeps a ray's seen mask in ONE vector register (windows of up to 2048 pixels) or TWO (up to 4096: lone_kernel<true>).  Random poses at
+    resolutions whose pixel windows end just below / above 2048 pixels and at odd offsets inside a mask word, both kernels against the oracle."""
+    rng = np.random.default_rng(60606)
+    ws = scenes.load_world("proc256")
+    for W, H in ((2047, 1031), (2049, 2050), (2500, 2113), (4096, 1500)):
+        ctx = contexts("proc256", W, H)
+        for i in range(4):
+            frac = rng.uniform(-0.2, 1.2, size=3)
+            frac[1] = rng.uniform(0.1, 1.1)
+            pos = [frac[k] * ws.dims[k] for k in range(3)]
+            eul = [rng.uniform(-89, 89), rng.uniform(0, 360), rng.choice([0.0, rng.uniform(0, 360)])]
+            fr = scenes.make_frame(ws, W, H, pos, eul, lod_error=float(rng.choice([1.0, 6.0])))
+            o_td, o_lr, _ = O.draw_segments(ws, fr, W, H, clear=CLEAR, counters=False)
+            for label, mode in BOTH_KERNELS:
+                g_td, g_lr = _render_gpu(ctx, fr, latency=mode)
+                _compare(f"wide {W}x{H} #{i} [{label}] pos={pos} eul={eul}", fr, g_td, g_lr, o_td, o_lr)
+
+
 def test_batch_equals_single_frames(contexts):
     """cvx_draw_segments_batch (many frames per launch, mixed iteration directions) == frame-by-frame draws."""
     ws = scenes.load_world("proc256")
