@@ -159,6 +159,9 @@ namespace CpuVox.Gpu
 		/// <summary>RenderManager.SetResolution (RenderManager.cs:94-109).</summary>
 		public void SetResolution(int resolutionX, int resolutionY) { Check(Native.cvx_set_resolution(ctx, resolutionX, resolutionY)); }
 
+		/// <summary>Which kernel a draw runs on: Native.CVX_LATENCY_AUTO (default: one blocking frame -> the latency kernel), _NEVER, _ALWAYS.</summary>
+		public void SetLatencyKernel(int mode) { Check(Native.cvx_set_latency_kernel(ctx, mode)); }
+
 		/// <summary>RenderManager.DrawSegments (RenderManager.cs:258-372); blocks like render.Complete().</summary>
 		public void DrawSegments(SegmentData* segments4, CameraData* camera, int screenWidth, int screenHeight, float vpX, float vpY, int bufferIndex)
 		{
