@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Event counts of the latency kernel (cvx_lone.h) per frame: python3 tools/lone_stats.py [poses] [width height] [world] [lod-error]
+"""Event counts of the latency kernel (cvx_lone.h) per frame: python3 tools/lone_stats.py [poses] [width height] [world] [lod-error]   (CVX_POSE_INDEX=i: that sample of the benchmark path, `poses` times)
 needs the counting variant: make -C cpuvox_amd/csrc variant NAME=lonestats DEFS=-DCVX_LONE_STATS"""
 import ctypes
 import os
@@ -30,7 +30,8 @@ acc = [0] * 48
 longest = [0] * 48
 lives = []
 for g in range(poses):
-    pos, eul = host.sample_benchmark_path(((g * 37) % 1000) / 1000 * host.BENCHMARK_PATH_LENGTH, ws.dims)
+    index = int(os.environ["CVX_POSE_INDEX"]) if "CVX_POSE_INDEX" in os.environ else (g * 37) % 1000
+    pos, eul = host.sample_benchmark_path(index / 1000 * host.BENCHMARK_PATH_LENGTH, ws.dims)
     ctx.draw_segments(host.setup_frame(host.camera_pose(pos, eul, W, H), lods, far, W, H, ws.dims[1]), 0)
     lib.cvx_debug_lone_stats(out, 1)
     for i in range(48):
