@@ -17,6 +17,11 @@
  * Threading: one caller thread per context (as the reference: Unity main
  * thread).  cvx_draw_segments is blocking like DrawSegments unless
  * CVX_DRAW_ASYNC is passed.
+ *
+ * Two kernels stand behind the draw calls and give the same raybuffers bit for
+ * bit: the latency kernel for the reference's own call pattern, one blocking
+ * frame at a time (one wavefront per ray), and the batch kernel for many
+ * frames per launch (one lane per ray); see cvx_set_latency_kernel.
  */
 #ifndef CPUVOX_GPU_H
 #define CPUVOX_GPU_H

@@ -820,9 +820,14 @@ def test_errors_are_reported_not_swallowed():
         ctx.width = 640
         ctx.draw_segments(fr, 0)
     ctx.width = 320
-    fr.camera.PositionY = float("nan")
-    with pytest.raises(gpu.CvxError):  # non-finite camera
-        ctx.draw_segments(fr, 0)
+    for mode in (gpu.LATENCY_ALWAYS, gpu.LATENCY_NEVER):  # (the checks sit in front of both kernels)
+        ctx.set_latency_kernel(mode)
+        fr.camera.PositionY = float("nan")
+        with pytest.raises(gpu.CvxError):  # non-finite camera
+            ctx.draw_segments(fr, 0)
+    with pytest.raises(gpu.CvxError):  # not a latency-kernel mode
+        ctx.set_latency_kernel(7)
+    ctx.set_latency_kernel(gpu.LATENCY_AUTO)
     # a world wider than the column loop's packed position (x * 65536 + z, cvx_kernels.h ColumnCursor) is refused at upload
     import ctypes as C
     blob = (C.c_uint8 * (65536 * 12))()
