@@ -29,6 +29,8 @@
 // contraction, x86 cvttss2si) is shared; results are bit-identical to render_kernel and to the CPU oracle (tests/test_gpu_parity.py, tools/soak.py).
 #pragma once
 
+#include <type_traits>
+
 #include "cvx_kernels.h"
 
 namespace cvxk {
@@ -67,6 +69,17 @@ __device__ unsigned long long g_loneLongest[48];
 __device__ __forceinline__ float rlf(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 __device__ __forceinline__ int rli(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ uint32_t rlu(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
+// vec with lane l replaced by the wave-uniform value: v_writelane_b32 (no compiler builtin in this toolchain).  A gfx9 vector instruction reads ONE scalar
+// register, so the lane select goes through M0 (one wait state after the scalar write of M0, as for the other readers of M0)
+// (M0 is the compiler's own: it loads M0 immediately before each of its uses -- here the LDS address of global_load_lds --, and the clobber tells it M0 is gone)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ uint32_t write_lane(uint32_t vec, uint32_t value, int l)
+{
+	asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(vec) : "s"(value), "s"(l) : "m0");
+	return vec;
+}
+#pragma clang diagnostic pop
 __device__ __forceinline__ lanemask_t lanes_from(int l) { return ~0ull << l; } // lanes >= l (l in 0..63)
 // A wave-uniform value the compiler cannot PROVE uniform (the result of an inline-asm instruction -- f2i, hw_min -- counts as divergent, and everything
 // computed from it, and every branch on that: exec-mask loops instead of scalar branches): read from the first lane, it is uniform by construction.
@@ -98,12 +111,21 @@ __device__ __forceinline__ uint32_t lone_word(const LoneSeen &s, int i)
 	return i < 64 ? a : (i < 128 ? b : 0xFFFFFFFFu);
 }
 
+// ... the word of a pixel inside [omin, omax]: held by the instance by construction (cvx_gpu.hip picks HI for windows of more than 64 words), no clamp
+template <bool HI>
+__device__ __forceinline__ uint32_t lone_word_of_pixel(const LoneSeen &s, int y)
+{
+	const int i = (y >> 5) - s.wordBase;
+	if (!HI) { return rlu(s.w0, i); }
+	return lone_word<HI>(s, i);
+}
+
 // first unseen pixel >= start, or omax + 1; start unchanged when start > omax (the reference's while loop at :407 / :678 does not run then)
 template <bool HI>
 __device__ __forceinline__ int lone_scan_up(const LoneSeen &s, int start, int omax)
 {
 	if (CVX_RARE(start > omax)) { return start; }
-	if (CVX_USUAL(((lone_word<HI>(s, (start >> 5) - s.wordBase) >> (start & 31)) & 1u) == 0u)) { return start; } // (the usual case: the pixel right above the run is unseen)
+	if (CVX_USUAL(((lone_word_of_pixel<HI>(s, start) >> (start & 31)) & 1u) == 0u)) { return start; } // (the usual case: the pixel right above the run is unseen)
 	const uint32_t m0 = ~s.w0 & range_mask_any(s.wordBase + s.lane, start, omax);
 	const lanemask_t b0 = __ballot(m0 != 0u);
 	if (b0 != 0ull) {
@@ -126,7 +148,7 @@ template <bool HI>
 __device__ __forceinline__ int lone_scan_down(const LoneSeen &s, int start, int omin)
 {
 	if (CVX_RARE(start < omin)) { return start; }
-	if (CVX_USUAL(((lone_word<HI>(s, (start >> 5) - s.wordBase) >> (start & 31)) & 1u) == 0u)) { return start; } // (the usual case: the pixel right below the run is unseen)
+	if (CVX_USUAL(((lone_word_of_pixel<HI>(s, start) >> (start & 31)) & 1u) == 0u)) { return start; } // (the usual case: the pixel right below the run is unseen)
 	if (HI) {
 		const uint32_t m1 = ~s.w1 & range_mask_any(s.wordBase + 64 + s.lane, omin, start);
 		const lanemask_t b1 = __ballot(m1 != 0u);
@@ -178,7 +200,7 @@ template <bool HI>
 __device__ __forceinline__ lanemask_t lone_unseen(const LoneSeen &s, int yb, int n)
 {
 	const int sh = yb & 31;
-	if (CVX_USUAL(sh + n <= 32)) { return (lanemask_t)((~lone_word<HI>(s, (yb >> 5) - s.wordBase) >> sh) & (0xFFFFFFFFu >> (32 - n))); }
+	if (CVX_USUAL(sh + n <= 32)) { return (lanemask_t)((~lone_word_of_pixel<HI>(s, yb) >> sh) & (0xFFFFFFFFu >> (32 - n))); }
 	return lone_unseen64<HI>(s, yb) & (n >= CVX_WAVE ? ~0ull : ((1ull << n) - 1ull));
 }
 
@@ -290,14 +312,6 @@ __device__ __forceinline__ RunProj project_run(f3 camSpaceMinLast, f3 camSpaceMa
 	P.faceBottom = faceBottom;
 	return P;
 }
-
-// flag bits of a lane's `flags` word, per run r (0 .. 2): bit r * 8 + ...
-#define CVX_LF_EXISTS 1u
-#define CVX_LF_SIDE 2u
-#define CVX_LF_FACENEAR 4u
-#define CVX_LF_FACETOP 8u
-#define CVX_LF_FACEBOTTOM 16u
-#define CVX_LF_LISTED (1u << 24) /* the column's runs live in the run list: processed with wave-uniform operands when its turn comes */
 
 // ---------------------------------------------------------------------------
 // One ray: TraceToFirstColumnJob + ExecuteRay by one wave.
@@ -510,65 +524,117 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 		runCidx[2] = runLen[0] + runLen[1];
 		RunProj P[3];
 		uint32_t faceColor[3];
-		uint32_t flags = listed ? CVX_LF_LISTED : 0u;
-		bool anyRun[3];
+		const lanemask_t listedMask = __ballot(listed); // columns whose runs live in the run list: looked at when their turn comes (processColumn)
+		lanemask_t topMask[3];                          // per run index: the columns whose run shows its top face (the others its bottom face, if any)
+		int runsInWindow = 1; // how many run indices the window's columns use (wave-uniform)
 #pragma unroll
 		for (int r = 0; r < 3; r++) {
 			const bool exists = r < code;
 			faceColor[r] = 0u;
 			P[r] = RunProj{};
-			anyRun[r] = r == 0 || __ballot(exists) != 0ull;
-			if (anyRun[r]) { CVX_LSTAT(2); // (wave-uniform: a window without a second / third run anywhere skips their projections)
+			topMask[r] = 0ull;
+			const bool anyRun = r == 0 || __ballot(exists) != 0ull;
+			if (anyRun) { CVX_LSTAT(2);
+				runsInWindow = r + 1; // (wave-uniform: a window without a second / third run anywhere skips their projections)
 				P[r] = project_run(camSpaceMinLast, camSpaceMaxLast, camSpaceMinNext, camSpaceMaxNext, (float)runB[r], (float)runT[r], runLen[r], cameraPosYNormalized, invWorldMaxY);
 				if (exists) {
 					// :553,560: the run's first colour for a top face, its last for a bottom face (read for every run: the address is a colour of this run either way)
 					faceColor[r] = ld_color(arena, colorsOff + ((uint32_t)(P[r].faceTop ? runCidx[r] : runCidx[r] + runLen[r] - 1) << L.colorShift));
 				}
-				const uint32_t f = (exists ? CVX_LF_EXISTS : 0u) | (P[r].sideVisible ? CVX_LF_SIDE : 0u) | (P[r].faceNear ? CVX_LF_FACENEAR : 0u) | (P[r].faceTop ? CVX_LF_FACETOP : 0u) |
-				                   (P[r].faceBottom ? CVX_LF_FACEBOTTOM : 0u);
-				flags |= (exists ? f : 0u) << (r * 8);
+				topMask[r] = __ballot(P[r].faceTop);
 			}
+			// What can never draw gets an EMPTY pixel range, so the overlap tests of the pass (:505 / :581) need no flags: a run the record does not hold, a
+			// side the near plane removed (:484), a face it removed (:566) or that the camera cannot see (neither top nor bottom, :549-565)
+			const bool sideCan = exists && P[r].sideVisible;
+			const bool faceCan = exists && P[r].faceNear && (P[r].faceTop || P[r].faceBottom);
+			P[r].rbMinS = sideCan ? P[r].rbMinS : 0x7FFFFFFF;
+			P[r].rbMaxS = sideCan ? P[r].rbMaxS : (int)0x80000000;
+			P[r].rbMinF = faceCan ? P[r].rbMinF : 0x7FFFFFFF;
+			P[r].rbMaxF = faceCan ? P[r].rbMaxF : (int)0x80000000;
 		}
 
 		CVX_LMARK("winsetup_end");
-		uint32_t todo = 0u;                    // (runTests, below)
+		lanemask_t todoMask = 0ull; // the columns with any such bit, and the columns of the run list
+		uint32_t todo = 0u; // (runTests, below) which runs of the lane's column can touch the ray's state: bit 2r = the side of run r, bit 2r + 1 = its face
 		float wbMin = 0.0f, wbMax = worldMaxY; // worldBoundsMin / Max of the lane's column (:283-284, narrowed by the cull :277-280 or set by the clip :392-393)
 
 		// ---- pixel loops (lane = pixel) ------------------------------------------------------------------------------------------------
 		// side of a run, :519-533: the unseen pixels of [rbMin, rbMax] get the run's perspective-correct colour
-		auto sidePixels = [&](int rbMin, int rbMax, float boundsX, float boundsY, float uvAx, float uvBx, float uvAy, float uvBy, int elementLength, int elementColorsIndex, uint32_t columnColorsOff) {
-			const TexRun texRun = tex_run(boundsX, boundsY, uvAx, uvBx, uvAy, uvBy);
+		// A pixel range inside ONE mask word (the usual case: a few pixels): the word comes out of its lane once (v_readlane), gives the unseen pixels of the
+		// range, and goes back with the range marked (v_writelane) -- no pass over the 64 words.  Returns false when the range spans words (the general loops).
+		auto oneWordRange = [&](int rbMin, int rbMax, lanemask_t &unseen) -> bool {
+			const int i = (rbMin >> 5) - seen.wordBase;
+			if (CVX_RARE(i != (rbMax >> 5) - seen.wordBase)) { return false; }
+			const int first = rbMin & 31;
+			const uint32_t range = ((2u << (rbMax - rbMin)) - 1u) << first;
+			if (!HI || i < CVX_WAVE) {
+				const uint32_t word = rlu(seen.w0, i);
+				unseen = (lanemask_t)((range & ~word) >> first);
+				if (unseen != 0ull) { seen.w0 = write_lane(seen.w0, word | range, i); }
+			} else {
+				const uint32_t word = rlu(seen.w1, i - CVX_WAVE);
+				unseen = (lanemask_t)((range & ~word) >> first);
+				if (unseen != 0ull) { seen.w1 = write_lane(seen.w1, word | range, i - CVX_WAVE); }
+			}
+			return true;
+		};
+		// (`operands` delivers the side's wave-uniform values -- v_readlanes of the column's lane -- and is only asked when a pixel is there to be written: more
+		// than a third of the sides that reach this point hold no unseen pixel)
+		struct SideOperands {
+			float boundsX, boundsY, uvAx, uvBx, uvAy, uvBy;
+			int elementLength, elementColorsIndex;
+			uint32_t columnColorsOff;
+		};
+		auto sidePixels = [&](int rbMin, int rbMax, auto operands) {
+			auto trip = [&](int yb, lanemask_t todo) {
+				CVX_LSTAT(3);
+				CVX_LSTAT_ADD(4, __popcll(todo));
+				frustumDirMaxWorld = CVX_FLOAT_EPSILON; // :522
+				const SideOperands o = operands();
+				const TexRun texRun = tex_run(o.boundsX, o.boundsY, o.uvAx, o.uvBx, o.uvAy, o.uvBy);
+				if (__builtin_amdgcn_inverse_ballot_w64(todo)) {
+					const int y = yb + lane;
+					bool certain;
+					int row = tex_row_cheap(y, o.boundsX, o.uvAx, o.uvAy, texRun, certain);
+					if (CVX_RARE(!certain)) { row = tex_row_exact(y, o.boundsX, o.boundsY, o.uvAx, o.uvBx, o.uvAy, o.uvBy); }
+					const int colorIdx = m_clampi(row, 0, o.elementLength - 1) + o.elementColorsIndex;
+					// the colour goes from memory STRAIGHT into the ray's row in LDS (global_load_lds_dword: lane p's dword lands at the LDS base + 4 p, and lane
+					// p IS pixel yb + p): no register, so nothing waits for the load until the row is read out at the end of the ray
+					__builtin_amdgcn_global_load_lds((const CVX_GLOBAL uint32_t *)(arena + (o.columnColorsOff + ((uint32_t)colorIdx << L.colorShift))),
+					                                 (__attribute__((address_space(3))) uint32_t *)(pix + yb), 4, 0, 0);
+				}
+			};
+			lanemask_t unseen;
+			if (CVX_USUAL(oneWordRange(rbMin, rbMax, unseen))) {
+				if (unseen != 0ull) { trip(rbMin, unseen); }
+				return;
+			}
 			for (int yb = rbMin; yb <= rbMax; yb += CVX_WAVE) {
 				const int n = min(CVX_WAVE, rbMax - yb + 1);
 				const lanemask_t todo = lone_unseen<HI>(seen, yb, n);
 				if (CVX_RARE(todo == 0ull)) { continue; }
-				CVX_LSTAT(3);
-				CVX_LSTAT_ADD(4, __popcll(todo));
-				frustumDirMaxWorld = CVX_FLOAT_EPSILON; // :522
-				if (__builtin_amdgcn_inverse_ballot_w64(todo)) {
-					const int y = yb + lane;
-					bool certain;
-					int row = tex_row_cheap(y, boundsX, uvAx, uvAy, texRun, certain);
-					if (CVX_RARE(!certain)) { row = tex_row_exact(y, boundsX, boundsY, uvAx, uvBx, uvAy, uvBy); }
-					const int colorIdx = m_clampi(row, 0, elementLength - 1) + elementColorsIndex;
-					// the colour goes from memory STRAIGHT into the ray's row in LDS (global_load_lds_dword: lane p's dword lands at the LDS base + 4 p, and lane
-					// p IS pixel yb + p): no register, so nothing waits for the load until the row is read out at the end of the ray
-					__builtin_amdgcn_global_load_lds((const CVX_GLOBAL uint32_t *)(arena + (columnColorsOff + ((uint32_t)colorIdx << L.colorShift))),
-					                                 (__attribute__((address_space(3))) uint32_t *)(pix + yb), 4, 0, 0);
-				}
+				trip(yb, todo);
 			}
 			lone_mark<HI>(seen, rbMin, rbMax);
 		};
 		// top / bottom of a run, :595-603
 		auto facePixels = [&](int rbMin, int rbMax, uint32_t color) {
-			for (int yb = rbMin; yb <= rbMax; yb += CVX_WAVE) {
-				const int n = min(CVX_WAVE, rbMax - yb + 1);
-				const lanemask_t todo = lone_unseen<HI>(seen, yb, n);
-				if (CVX_RARE(todo == 0ull)) { continue; }
+			auto trip = [&](int yb, lanemask_t todo) {
 				CVX_LSTAT(5);
 				CVX_LSTAT_ADD(6, __popcll(todo));
 				frustumDirMaxWorld = CVX_FLOAT_EPSILON; // :598
 				if (__builtin_amdgcn_inverse_ballot_w64(todo)) { pix[yb + lane] = color; }
+			};
+			lanemask_t unseen;
+			if (CVX_USUAL(oneWordRange(rbMin, rbMax, unseen))) {
+				if (unseen != 0ull) { trip(rbMin, unseen); }
+				return;
+			}
+			for (int yb = rbMin; yb <= rbMax; yb += CVX_WAVE) {
+				const int n = min(CVX_WAVE, rbMax - yb + 1);
+				const lanemask_t todo = lone_unseen<HI>(seen, yb, n);
+				if (CVX_RARE(todo == 0ull)) { continue; }
+				trip(yb, todo);
 			}
 			lone_mark<HI>(seen, rbMin, rbMax);
 		};
@@ -584,7 +650,9 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 					lone_reduce_pixel_horizon<HI>(seen, omin, omax, rbMin, rbMax, nextFreePixelMin, nextFreePixelMax, frustumBoundsMin, frustumBoundsMax);
 					CVX_LMARK("sidereduce_end");
 					CVX_LSECE(8);
-					if (rbMin <= rbMax) { sidePixels(rbMin, rbMax, R.boundsX, R.boundsY, R.uvAx, R.uvBx, R.uvAy, R.uvBy, elementLength, elementColorsIndex, columnColorsOff); }
+					if (rbMin <= rbMax) {
+						sidePixels(rbMin, rbMax, [&]() { return SideOperands{ R.boundsX, R.boundsY, R.uvAx, R.uvBx, R.uvAy, R.uvBy, elementLength, elementColorsIndex, columnColorsOff }; });
+					}
 					if (nextFreePixelMin > nextFreePixelMax) { alive = false; return; } // :535-539
 					CVX_LMARK("sidepixels_end");
 					CVX_LSECE(6);
@@ -618,16 +686,21 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 			if (HI) { clean = clean && __ballot((seen.w1 & range_mask_any(seen.wordBase + 64 + lane, nextFreePixelMin, nextFreePixelMax)) != 0u) == 0ull; }
 			return clean;
 		};
-		auto mayHoldUnseen = [&](int lo, int hi) -> bool {
-			const int i = (lo >> 5) - seen.wordBase, first = lo & 31;
+		auto gatherWord = [&](int lo) -> uint32_t { // the mask word that holds pixel lo, from the lane that has it
+			const int i = (lo >> 5) - seen.wordBase;
 			uint32_t word = (uint32_t)__builtin_amdgcn_ds_bpermute((i & 63) << 2, (int)seen.w0);
 			if (HI) {
 				const uint32_t word1 = (uint32_t)__builtin_amdgcn_ds_bpermute((i & 63) << 2, (int)seen.w1);
 				word = i < CVX_WAVE ? word : word1;
 			}
+			return word;
+		};
+		auto holdsUnseen = [&](uint32_t word, int lo, int hi) -> bool {
+			const int first = lo & 31;
 			const int more = min(hi - lo, 31 - first); // pixels of the range in this word, less one
 			return ((int)((hi - lo) > more) | (int)(((~word >> first) << (31 - more)) != 0u)) != 0;
 		};
+		auto mayHoldUnseen = [&](int lo, int hi) -> bool { return holdsUnseen(gatherWord(lo), lo, hi); };
 
 		// ---- element loop (:424-611) of column j, run by run in the reference's walk order, with the ray's current state
 		auto processColumn = [&](int j) {
@@ -641,7 +714,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 			}
 #endif
 			const uint32_t bits = rlu(todo, j);
-			if (CVX_RARE((bits & 0x80000000u) != 0u)) {
+			if (CVX_RARE(((listedMask >> j) & 1ull) != 0ull)) {
 				CVX_LSTAT(10);
 				// A column of the run list (cvx_device.h: a few per thousand of a built terrain, most columns of a model world such as mill.obj -- ten thin runs
 				// and more per column --, every column of a foreign blob).  Here the lanes are the column's RUNS, 64 at a time in the reference's walk order
@@ -715,8 +788,10 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 						CVX_LMARK("sidereduce_end");
 						CVX_LSECE(8);
 						if (CVX_USUAL(rbMin <= rbMax)) {
-							sidePixels(rbMin, rbMax, rlf(P[r].boundsX, j), rlf(P[r].boundsY, j), rlf(P[r].uvAx, j), rlf(P[r].uvBx, j), rlf(P[r].uvAy, j), rlf(P[r].uvBy, j), rli(runLen[r], j), rli(runCidx[r], j),
-							           rlu(colorsOff, j));
+							sidePixels(rbMin, rbMax, [&]() {
+								return SideOperands{ rlf(P[r].boundsX, j), rlf(P[r].boundsY, j), rlf(P[r].uvAx, j), rlf(P[r].uvBx, j), rlf(P[r].uvAy, j), rlf(P[r].uvBy, j), rli(runLen[r], j), rli(runCidx[r], j),
+								                     rlu(colorsOff, j) };
+							});
 						}
 						if (CVX_RARE(nextFreePixelMin > nextFreePixelMax)) { alive = false; return; } // :535-539
 						CVX_LMARK("sidepixels_end");
@@ -760,15 +835,18 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 			const float px_ = planeDir.x * dist, pz_ = planeDir.z * dist;
 			const float pMinX = planeStartBottom.x + px_, pMinZ = planeStartBottom.z + pz_, pMaxX = planeStartTop.x + px_, pMaxZ = planeStartTop.z + pz_;
 			// GetWorldBoundsClippingCamSpace, CameraData.cs:51-99 (the flattened form of clip_world_bounds)
-			const bool a1 = pMinX > pMinZ * frustumBoundsMax;
-			const bool a2 = pMaxX > pMaxZ * frustumBoundsMax;
-			const bool b1 = pMinX < pMinZ * frustumBoundsMin;
-			const bool b2 = pMaxX < pMaxZ * frustumBoundsMin;
-			const bool n1 = !a1, n2 = !a2;
-			const bool straddles = CVX_AND(CVX_AND(n1, b1), a2);
-			const bool need = roleMax ? CVX_OR(CVX_AND(a1, b2), CVX_AND(n1, CVX_OR(a2, b2))) : CVX_OR(a1, b1);
-			const bool againstMax = roleMax ? CVX_AND(n1, a2) : a1; // which window bound this lane's clip is made against
-			const bool clipped = CVX_OR(CVX_AND(a1, a2), CVX_AND(CVX_AND(n1, n2), CVX_AND(b1, b2)));
+			// (the boolean algebra on the ballots, 64-bit scalars: a select between per-lane booleans would be made in vector registers)
+			const lanemask_t roleMaxBits = 0xAAAAAAAAAAAAAAAAull;
+			const lanemask_t a1 = __ballot(pMinX > pMinZ * frustumBoundsMax);
+			const lanemask_t a2 = __ballot(pMaxX > pMaxZ * frustumBoundsMax);
+			const lanemask_t b1 = __ballot(pMinX < pMinZ * frustumBoundsMin);
+			const lanemask_t b2 = __ballot(pMaxX < pMaxZ * frustumBoundsMin);
+			const lanemask_t straddleBits = ~a1 & b1 & a2;
+			const lanemask_t needBits = (roleMaxBits & ((a1 & b2) | (~a1 & (a2 | b2)))) | (~roleMaxBits & (a1 | b1));
+			const lanemask_t againstMaxBits = (roleMaxBits & ~a1 & a2) | (~roleMaxBits & a1); // which window bound this lane's clip is made against
+			const lanemask_t clippedBits = (a1 & a2) | (~a1 & ~a2 & b1 & b2);
+			const bool need = __builtin_amdgcn_inverse_ballot_w64(needBits);
+			const bool againstMax = __builtin_amdgcn_inverse_ballot_w64(againstMaxBits);
 			const float finv = quot_safe(1.0f, recip_safe(againstMax ? frustumBoundsMax : frustumBoundsMin)); // CameraData.cs:103,111
 			const float c0 = 1.0f * pMaxZ - finv * pMaxX;
 			const float c1 = 1.0f * pMinZ - finv * pMinX;
@@ -776,14 +854,13 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 			const float q = num / (num - oth);
 			const float clipT = roleMax ? q : 1.0f - q; // clip_max: c1 / (c1 - c0); clip_min: 1 - c0 / (c0 - c1)
 			const float lerpT = need ? clipT : (roleMax ? 1.0f : 0.0f);
-			const lanemask_t clippedBits = __ballot(clipped), straddleBits = __ballot(straddles);
 			const bool clippedLast = (clippedBits & 1ull) != 0ull, clippedNext = (clippedBits & 4ull) != 0ull;
 			if (!(straddleBits & 1ull) || !(straddleBits & 4ull)) { CVX_LSTAT(12); }
 			// :300-390: each bound from the Last or the Next intersection
 			const float otherT = quadSwapNext(lerpT);
 			const float lastT = roleNext ? otherT : lerpT, nextT = roleNext ? lerpT : otherT;
-			const bool closer = roleMax ? lastT > nextT : lastT < nextT;
-			const bool fromLast = !clippedLast && (clippedNext || closer);
+			const lanemask_t closerBits = (roleMaxBits & __ballot(lastT > nextT)) | (~roleMaxBits & __ballot(lastT < nextT));
+			const bool fromLast = __builtin_amdgcn_inverse_ballot_w64(clippedLast ? 0ull : (clippedNext ? ~0ull : closerBits));
 			float worldBounds = m_lerp(0.0f, worldMaxY, fromLast ? lastT : nextT);
 			const float dir = (worldBounds - posY) / (fromLast ? dL : dN);
 			worldBounds = roleMax ? ceilf(worldBounds) : floorf(worldBounds);
@@ -799,7 +876,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 			// on its bound -- then :337-421 change nothing
 			const float ptX = pMinX + (pMaxX - pMinX) * lerpT, ptZ = pMinZ + (pMaxZ - pMinZ) * lerpT;
 			const bool onBound = fabsf(ptX - (roleMax ? frustumBoundsMax : frustumBoundsMin) * ptZ) < 0.4f * fabsf(ptZ);
-			const bool windowUntouched = (__ballot(straddles && onBound) & 0xFull) == 0xFull;
+			const bool windowUntouched = (straddleBits & __ballot(onBound) & 0xFull) == 0xFull;
 			CVX_LMARK("clip_end");
 			if (!CVX_USUAL(windowUntouched)) {
 				CVX_LSTAT(13);
@@ -835,22 +912,58 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 		// of run r, bit 2r + 1 = its face, bit 31 = a column of the run list (looked at when its turn comes).
 		// A run's side / face has to overlap the window (:505 / :581) and to hold an unseen pixel (windowIsClean / mayHoldUnseen above: one test for the run's
 		// side and face together).
-		auto runTests = [&]() {
-			todo = (flags & CVX_LF_LISTED) != 0u ? 0x80000000u : 0u;
+		// (the gathers of all runs are issued before the first is looked at: one LDS round trip per pass, not one per run)
+		// (the boolean algebra is written on the ballots -- 64-bit scalars --: selects and merges of per-lane booleans would be made in vector registers)
+		auto runTestsOf = [&](auto runsConstant) {
+			constexpr int runs = decltype(runsConstant)::value;
 			const bool windowClean = windowIsClean();
+			int loS[runs], hiS[runs], loF[runs], hiF[runs];
+			lanemask_t sideBits[runs], faceBits[runs];
 #pragma unroll
-			for (int r = 0; r < 3; r++) {
-				if (r > 0 && !anyRun[r]) { continue; } // (wave-uniform: no column of the window has such a run)
-				const uint32_t f = flags >> (r * 8);
+			for (int r = 0; r < runs; r++) {
 				const float b = (float)runB[r], t = (float)runT[r];
-				const bool in = ((int)((f & CVX_LF_EXISTS) != 0u) & (int)!(b > wbMax) & (int)!(t < wbMin)) != 0;                                                  // :461-475
-				const int loS = max(P[r].rbMinS, nextFreePixelMin), hiS = min(P[r].rbMaxS, nextFreePixelMax), loF = max(P[r].rbMinF, nextFreePixelMin), hiF = min(P[r].rbMaxF, nextFreePixelMax);
-				const bool side = ((int)in & (int)((f & CVX_LF_SIDE) != 0u) & (int)(loS <= hiS)) != 0;                                                           // :505
-				const bool wanted = (((int)((f & CVX_LF_FACETOP) != 0u) & (int)!(t > wbMax)) | ((int)((f & CVX_LF_FACEBOTTOM) != 0u) & (int)!(b < wbMin))) != 0; // :549-565
-				const bool face = ((int)in & (int)wanted & (int)((f & CVX_LF_FACENEAR) != 0u) & (int)(loF <= hiF)) != 0;                                         // :581
-				bool writable = true;
-				if (!windowClean) { writable = mayHoldUnseen(side ? (face ? min(loS, loF) : loS) : loF, side ? (face ? max(hiS, hiF) : hiS) : hiF); }
-				todo |= ((int)side & (int)writable ? 1u << (2 * r) : 0u) | ((int)face & (int)writable ? 2u << (2 * r) : 0u);
+				const lanemask_t in = __ballot(!(b > wbMax)) & __ballot(!(t < wbMin)); // :461-475
+				loS[r] = max(P[r].rbMinS, nextFreePixelMin);
+				hiS[r] = min(P[r].rbMaxS, nextFreePixelMax);
+				loF[r] = max(P[r].rbMinF, nextFreePixelMin);
+				hiF[r] = min(P[r].rbMaxF, nextFreePixelMax);
+				sideBits[r] = in & __ballot(loS[r] <= hiS[r]);                                                                  // :484, :505 (an invisible side has an empty range)
+				const lanemask_t wanted = (topMask[r] & __ballot(!(t > wbMax))) | (~topMask[r] & __ballot(!(b < wbMin))); // :549-565 (a face that is neither has an empty range)
+				faceBits[r] = in & wanted & __ballot(loF[r] <= hiF[r]);                                                         // :566, :581
+			}
+			if (!windowClean) {
+				int lo[runs], hi[runs];
+				uint32_t word[runs];
+#pragma unroll
+				for (int r = 0; r < runs; r++) {
+					const bool side = __builtin_amdgcn_inverse_ballot_w64(sideBits[r]), face = __builtin_amdgcn_inverse_ballot_w64(faceBits[r]);
+					lo[r] = side ? (face ? min(loS[r], loF[r]) : loS[r]) : loF[r];
+					hi[r] = side ? (face ? max(hiS[r], hiF[r]) : hiS[r]) : hiF[r];
+					word[r] = gatherWord(lo[r]);
+				}
+#pragma unroll
+				for (int r = 0; r < runs; r++) {
+					const lanemask_t writable = __ballot(holdsUnseen(word[r], lo[r], hi[r]));
+					sideBits[r] &= writable;
+					faceBits[r] &= writable;
+				}
+			}
+			todo = 0u;
+#pragma unroll
+			for (int r = 0; r < runs; r++) {
+				todo |= (__builtin_amdgcn_inverse_ballot_w64(sideBits[r]) ? 1u << (2 * r) : 0u) | (__builtin_amdgcn_inverse_ballot_w64(faceBits[r]) ? 2u << (2 * r) : 0u);
+			}
+			todoMask = listedMask;
+#pragma unroll
+			for (int r = 0; r < runs; r++) { todoMask |= sideBits[r] | faceBits[r]; }
+		};
+		auto runTests = [&]() { // (wave-uniform: how many run indices the window's columns use)
+			if (runsInWindow == 3) {
+				runTestsOf(std::integral_constant<int, 3>{});
+			} else if (runsInWindow == 2) {
+				runTestsOf(std::integral_constant<int, 2>{});
+			} else {
+				runTestsOf(std::integral_constant<int, 1>{});
 			}
 		};
 		lanemask_t hits = 0ull, leftWorldMask = 0ull;
@@ -862,26 +975,26 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 			const float columnWorldMax = (float)(rec.y >> 16);
 			const float newMax = posY + hw_max(frustumDirMaxWorld * wDistNext, frustumDirMaxWorld * wDistLast);
 			const float newMin = posY + hw_min(frustumDirMinWorld * wDistNext, frustumDirMinWorld * wDistLast);
-			const bool own = lane == clipped;
-			const bool leftWorld = ((int)nonEmpty & (int)!own & ((int)(newMin > worldMaxY) | (int)(newMax < 0.0f))) != 0;
-			const bool noOverlap = ((int)!own & ((int)(columnWorldMin > newMax) | (int)(columnWorldMax < newMin))) != 0;
-			const bool draw = ((int)nonEmpty & (int)!leftWorld & (int)!noOverlap) != 0;
+			const lanemask_t ownBits = clipped >= 0 ? 1ull << clipped : 0ull;
+			const bool own = __builtin_amdgcn_inverse_ballot_w64(ownBits);
+			const lanemask_t leftWorldBits = nonEmptyMask & ~ownBits & (__ballot(newMin > worldMaxY) | __ballot(newMax < 0.0f));
+			const lanemask_t noOverlapBits = ~ownBits & (__ballot(columnWorldMin > newMax) | __ballot(columnWorldMax < newMin));
 			wbMin = own ? wbMin : newMin;
 			wbMax = own ? wbMax : newMax;
 			runTests();
 			const lanemask_t range = lanes_from(from);
-			hits = __ballot(draw && todo != 0u) & range;
-			leftWorldMask = __ballot(leftWorld) & range;
+			hits = nonEmptyMask & ~leftWorldBits & ~noOverlapBits & todoMask & range;
+			leftWorldMask = leftWorldBits & range;
 			CVX_LMARK("filter_end");
 			CVX_LSECE(0);
 		};
 
-		CVX_LSEC(0);
-#ifdef CVX_LONE_TIMES /* ... and for the face colours */
+		// The window's face colours have to be there before the events start: left to the compiler, the wait (vmcnt(0): it cannot count what is in flight
+		// across the loop) sits in front of every face's colour read -- and there it also drains the side colours the column's side trip has just sent on
+		// their way into the LDS row, a full memory round trip per face.  Here it costs the tail of ONE round trip per window.
 		CVX_LSEC(13);
 		__builtin_amdgcn_s_waitcnt(0x0F70);
 		CVX_LSEC(0);
-#endif
 		// ---- the events of the window, in column order
 		int next = 0;         // first lane not yet looked at
 		bool hitsValid = false;
