@@ -70,13 +70,13 @@ __device__ __forceinline__ float rlf(float v, int l) { return __int_as_float(__b
 __device__ __forceinline__ int rli(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ uint32_t rlu(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 // vec with lane l replaced by the wave-uniform value: v_writelane_b32 (no compiler builtin in this toolchain).  A gfx9 vector instruction reads ONE scalar
-// register, so the lane select goes through M0 (one wait state after the scalar write of M0, as for the other readers of M0)
+// register, so the lane select goes through M0 (written by a scalar instruction: no wait state -- those are for lane selects written by vector instructions)
 // (M0 is the compiler's own: it loads M0 immediately before each of its uses -- here the LDS address of global_load_lds --, and the clobber tells it M0 is gone)
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ uint32_t write_lane(uint32_t vec, uint32_t value, int l)
 {
-	asm("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(vec) : "s"(value), "s"(l) : "m0");
+	asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(vec) : "s"(value), "s"(l) : "m0");
 	return vec;
 }
 #pragma clang diagnostic pop
@@ -171,13 +171,15 @@ template <bool HI>
 __device__ __forceinline__ void lone_reduce_pixel_horizon(const LoneSeen &s, int omin, int omax, int &rbMin, int &rbMax, int &nfMin, int &nfMax, float &frustumBoundsMin,
                                                           float &frustumBoundsMax)
 {
-	const bool raiseMin = rbMin <= nfMin && rbMax >= nfMin;
+	// (the callers have tested the overlap, rbMax >= nfMin && rbMin <= nfMax (:505 / :581), and a ray whose window is empty has ended: nfMin <= nfMax; so of the
+	// reference's two conjunctions, `rbMin <= nfMin && rbMax >= nfMin` and `rbMax >= nfMax && max(rbMin, nfMin) <= nfMax`, the second halves are true)
+	const bool raiseMin = rbMin <= nfMin;
 	rbMin = max(rbMin, nfMin);
 	if (raiseMin) {
 		nfMin = lone_scan_up<HI>(s, rbMax + 1, omax);
 		frustumBoundsMin = (float)nfMin - 0.501f;
 	}
-	const bool lowerMax = rbMax >= nfMax && rbMin <= nfMax;
+	const bool lowerMax = rbMax >= nfMax;
 	rbMax = min(rbMax, nfMax);
 	if (lowerMax) {
 		nfMax = lone_scan_down<HI>(s, rbMin - 1, omin);
@@ -317,8 +319,8 @@ __device__ __forceinline__ RunProj project_run(f3 camSpaceMinLast, f3 camSpaceMa
 // One ray: TraceToFirstColumnJob + ExecuteRay by one wave.
 // ---------------------------------------------------------------------------
 template <int DIR, bool HI>
-__device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegment &S, const DevWorld *__restrict__ world, int planeRayIndex, uint32_t *pix /* LDS: pix[y] = pixel y of the ray's row */,
-                                               LoneSeen &seen, uint32_t *merged /* 64 words of LDS */, unsigned int *stat_)
+__device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegment &S, const DevWorld *__restrict__ world, int planeRayIndex,
+                                               LoneSeen &seen, uint32_t *merged /* LDS: 64 words, then the ray's pixel row: pixel y at merged[64 + y - omin] */, unsigned int *stat_)
 {
 	(void)stat_;
 	const int lane = seen.lane;
@@ -362,6 +364,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 	ray.distLast = uni(ray.distLast); ray.distNext = uni(ray.distNext);
 	lod = uni(lod);
 	lodMax = uni(lodMax);
+	const int dirFlags = uni((dirXNonNegative ? 1 : 0) | (dirZNonNegative ? 2 : 0)); // (one scalar register instead of two lane masks for the life of the ray)
 
 	// ---- ExecuteRay, :195-620
 	int voxelScale = 1 << lod;
@@ -398,7 +401,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 
 	// column 0: LOD check (:237-243), bounds test (World.GetVoxelColumn, World.cs:130-142)
 	if (ray.distLast >= lodMax) {
-		dda_next_lod(ray, voxelScale, dirXNonNegative, dirZNonNegative);
+		dda_next_lod(ray, voxelScale, (dirFlags & 1) != 0, (dirFlags & 2) != 0);
 		lod++;
 		voxelScale *= 2;
 		L = world->level[lod];
@@ -601,7 +604,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 					// the colour goes from memory STRAIGHT into the ray's row in LDS (global_load_lds_dword: lane p's dword lands at the LDS base + 4 p, and lane
 					// p IS pixel yb + p): no register, so nothing waits for the load until the row is read out at the end of the ray
 					__builtin_amdgcn_global_load_lds((const CVX_GLOBAL uint32_t *)(arena + (o.columnColorsOff + ((uint32_t)colorIdx << L.colorShift))),
-					                                 (__attribute__((address_space(3))) uint32_t *)(pix + yb), 4, 0, 0);
+					                                 (__attribute__((address_space(3))) uint32_t *)(merged + (CVX_WAVE + (yb - omin))), 4, 0, 0);
 				}
 			};
 			lanemask_t unseen;
@@ -623,7 +626,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 				CVX_LSTAT(5);
 				CVX_LSTAT_ADD(6, __popcll(todo));
 				frustumDirMaxWorld = CVX_FLOAT_EPSILON; // :598
-				if (__builtin_amdgcn_inverse_ballot_w64(todo)) { pix[yb + lane] = color; }
+				if (__builtin_amdgcn_inverse_ballot_w64(todo)) { merged[CVX_WAVE + (yb - omin) + lane] = color; }
 			};
 			lanemask_t unseen;
 			if (CVX_USUAL(oneWordRange(rbMin, rbMax, unseen))) {
@@ -686,21 +689,21 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 			if (HI) { clean = clean && __ballot((seen.w1 & range_mask_any(seen.wordBase + 64 + lane, nextFreePixelMin, nextFreePixelMax)) != 0u) == 0ull; }
 			return clean;
 		};
-		auto gatherWord = [&](int lo) -> uint32_t { // the mask word that holds pixel lo, from the lane that has it
+		auto gatherWord = [&](int lo) -> uint32_t { // the mask word that holds pixel lo, from the lane that has it (ds_bpermute reads the lane from address bits [7:2])
 			const int i = (lo >> 5) - seen.wordBase;
-			uint32_t word = (uint32_t)__builtin_amdgcn_ds_bpermute((i & 63) << 2, (int)seen.w0);
+			uint32_t word = (uint32_t)__builtin_amdgcn_ds_bpermute(i << 2, (int)seen.w0);
 			if (HI) {
-				const uint32_t word1 = (uint32_t)__builtin_amdgcn_ds_bpermute((i & 63) << 2, (int)seen.w1);
+				const uint32_t word1 = (uint32_t)__builtin_amdgcn_ds_bpermute(i << 2, (int)seen.w1);
 				word = i < CVX_WAVE ? word : word1;
 			}
 			return word;
 		};
-		auto holdsUnseen = [&](uint32_t word, int lo, int hi) -> bool {
+		auto holdsUnseen = [&](uint32_t word, int lo, int hi) -> lanemask_t { // (as a ballot)
 			const int first = lo & 31;
 			const int more = min(hi - lo, 31 - first); // pixels of the range in this word, less one
-			return ((int)((hi - lo) > more) | (int)(((~word >> first) << (31 - more)) != 0u)) != 0;
+			return __ballot((hi - lo) > more) | __ballot(((~word >> first) << (31 - more)) != 0u);
 		};
-		auto mayHoldUnseen = [&](int lo, int hi) -> bool { return holdsUnseen(gatherWord(lo), lo, hi); };
+		auto mayHoldUnseen = [&](int lo, int hi) -> bool { return __builtin_amdgcn_inverse_ballot_w64(holdsUnseen(gatherWord(lo), lo, hi)); };
 
 		// ---- element loop (:424-611) of column j, run by run in the reference's walk order, with the ray's current state
 		auto processColumn = [&](int j) {
@@ -943,7 +946,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 				}
 #pragma unroll
 				for (int r = 0; r < runs; r++) {
-					const lanemask_t writable = __ballot(holdsUnseen(word[r], lo[r], hi[r]));
+					const lanemask_t writable = holdsUnseen(word[r], lo[r], hi[r]);
 					sideBits[r] &= writable;
 					faceBits[r] &= writable;
 				}
@@ -995,11 +998,14 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 		CVX_LSEC(13);
 		__builtin_amdgcn_s_waitcnt(0x0F70);
 		CVX_LSEC(0);
+		// `frustumDirMaxWorld == float.Epsilon` (:261): the sentinel is the one positive float with the bit pattern 1 (denormals are not flushed), so the
+		// wave-uniform comparison can be a scalar integer one (gfx9 has no scalar float compare)
+		auto directionsGone = [&]() -> bool { return __float_as_int(frustumDirMaxWorld) == 1; };
 		// ---- the events of the window, in column order
 		int next = 0;         // first lane not yet looked at
 		bool hitsValid = false;
 		while (alive) {
-			if (frustumDirMaxWorld == CVX_FLOAT_EPSILON) {
+			if (directionsGone()) {
 				// no valid frustum directions (:261 false): no cull -- the next non-empty column is drawn (:251-256), clipped first when it lies beyond 2 units (:295)
 				const lanemask_t rem = next < CVX_WAVE ? (nonEmptyMask & lanes_from(next)) : 0ull;
 				if (rem == 0ull) { break; }
@@ -1015,7 +1021,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 						CVX_LSTAT(21);
 						processColumn(j);
 						CVX_LSECE(0);
-						if (frustumDirMaxWorld == CVX_FLOAT_EPSILON) { hitsValid = false; }
+						if (directionsGone()) { hitsValid = false; }
 					}
 					next = j + 1;
 				} else {
@@ -1040,7 +1046,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 				processColumn(fh);
 				CVX_LSECE(0);
 				next = fh + 1;
-				if (frustumDirMaxWorld == CVX_FLOAT_EPSILON) { hitsValid = false; } // a pixel was written: the directions are gone (:522,598)
+				if (directionsGone()) { hitsValid = false; } // a pixel was written: the directions are gone (:522,598)
 			}
 		}
 		if (!alive || endCode == 1) { break; }
@@ -1049,7 +1055,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 			ray.pz = pos & 0xFFFF;
 			ray.sx = posStepX >> 16;
 			ray.sz = posStepZ;
-			dda_next_lod(ray, voxelScale, dirXNonNegative, dirZNonNegative);
+			dda_next_lod(ray, voxelScale, (dirFlags & 1) != 0, (dirFlags & 2) != 0);
 			lod++;
 			voxelScale *= 2;
 			L = world->level[lod];
@@ -1106,9 +1112,9 @@ __global__ __launch_bounds__(CVX_WAVE, CVX_LONE_WAVES_PER_SIMD) void lone_kernel
 	unsigned int *stat_ = nullptr;
 #endif
 	if (F.inverse) { // RenderJob.Execute :174-178
-		lone_trace_ray<-1, HI>(F, S, world, planeRayIndex, pix, seen, merged, stat_);
+		lone_trace_ray<-1, HI>(F, S, world, planeRayIndex, seen, merged, stat_);
 	} else {
-		lone_trace_ray<1, HI>(F, S, world, planeRayIndex, pix, seen, merged, stat_);
+		lone_trace_ray<1, HI>(F, S, world, planeRayIndex, seen, merged, stat_);
 	}
 #ifdef CVX_LONE_STATS
 	stat_[16]++;
