@@ -22,7 +22,7 @@ import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LLVM = "/opt/rocm/lib/llvm/bin"
-OTHER_SOURCES = ["cvx_world.hip", "cvx_shard.hip"]
+OTHER_SOURCES = ["cvx_lone.hip", "cvx_world.hip", "cvx_shard.hip"]
 
 
 def run(cmd, cwd):

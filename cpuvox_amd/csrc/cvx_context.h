@@ -132,6 +132,9 @@ inline bool IsPow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 // later is covered here.  *solidRuns receives the number of solid runs, *colourCount (optional) the number of colours the runs address.
 int ValidateColumn(cvx_context *ctx, int64_t i, const RefHeader &h, const uint32_t *elements, int64_t elementCount, int maxY, size_t *solidRuns, int64_t *colourCount = nullptr);
 
+// cvx_lone.hip (its own translation unit: the latency kernel is compiled with its own optimisation level, Makefile): launches lone_kernel<hi> with one
+// workgroup per ray (rays = 64 x tiles), `ldsBytes` of dynamic LDS (merge buffer + the ray's pixel row)
+void LaunchLone(bool hi, unsigned rays, size_t ldsBytes, hipStream_t stream, const DevFrame *frames, const DevTile *tiles, const DevWorld *world);
 } // namespace cvxi
 
 #define CVX_HIP(ctx, call)                                                                                              \

@@ -18,7 +18,6 @@
 #include "cvx_context.h"
 #include "cpuvox_gpu_diag.h"
 #include "cvx_kernels.h"
-#include "cvx_lone.h"
 
 namespace {
 std::string g_createError; // cvx_last_error(NULL)
@@ -434,9 +433,9 @@ int Launch(cvx_context *ctx, int frameCount, int flags)
 		if (ctx->countersEnabled) {
 			hipLaunchKernelGGL((cvxk::render_kernel<true>), grid, block, ldsBytes, ctx->stream, ctx->devFrames, ctx->devTiles, ctx->devWorld, ctx->devCounters);
 		} else if (ctx->launchLone == 1) { // one wave per ray, lanes = columns (cvx_lone.h): the single interactive frame
-			hipLaunchKernelGGL((cvxk::lone_kernel<false>), grid, block, loneLdsBytes, ctx->stream, ctx->devFrames, ctx->devTiles, ctx->devWorld);
+			cvxi::LaunchLone(false, grid.x, loneLdsBytes, ctx->stream, ctx->devFrames, ctx->devTiles, ctx->devWorld);
 		} else if (ctx->launchLone == 2) { // ... windows of more than 2048 pixels (4K)
-			hipLaunchKernelGGL((cvxk::lone_kernel<true>), grid, block, loneLdsBytes, ctx->stream, ctx->devFrames, ctx->devTiles, ctx->devWorld);
+			cvxi::LaunchLone(true, grid.x, loneLdsBytes, ctx->stream, ctx->devFrames, ctx->devTiles, ctx->devWorld);
 		} else {
 			hipLaunchKernelGGL((cvxk::render_kernel<false>), grid, block, ldsBytes, ctx->stream, ctx->devFrames, ctx->devTiles, ctx->devWorld, ctx->devCounters);
 		}
@@ -746,6 +745,9 @@ int DrawBatch(cvx_context *ctx, int frameCount, const cvx_segment_data *segments
 				std::reverse(order.begin(), order.end());
 			} else if (!std::strcmp(v, "frame")) {
 				for (size_t i = 0; i < n; i++) { order[i] = (uint32_t)i; }
+			} else if (!std::strncmp(v, "snake", 5) && std::atoi(v + 5) > 0) { // every other block of N tiles reversed: long and short tiles alternate on the units the blocks land on
+				const size_t period = (size_t)std::atoi(v + 5);
+				for (size_t at = period; at < n; at += 2 * period) { std::reverse(order.begin() + (ptrdiff_t)at, order.begin() + (ptrdiff_t)std::min(n, at + period)); }
 			} else if (!std::strcmp(v, "random")) {
 				uint32_t state = 12345u;
 				for (size_t i = n; i > 1; i--) {
@@ -1303,22 +1305,6 @@ int cvx_copy_rows(cvx_context *ctx, void *hipStream, int toPacked, int64_t spanC
 	CVX_HIP(ctx, hipGetLastError());
 	return CVX_OK;
 }
-
-#ifdef CVX_LONE_STATS /* diagnostic variant only (tools/lone_stats.py): event counts of the latency kernel, accumulated over all launches */
-int cvx_debug_lone_stats(uint64_t out[96], int reset)
-{
-	unsigned long long tmp[48];
-	if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(tmp, HIP_SYMBOL(cvxk::g_loneStats), sizeof tmp) != hipSuccess) { return CVX_ERR_HIP; }
-	for (int i = 0; i < 48; i++) { out[i] = tmp[i]; }
-	if (hipMemcpyFromSymbol(tmp, HIP_SYMBOL(cvxk::g_loneLongest), sizeof tmp) != hipSuccess) { return CVX_ERR_HIP; }
-	for (int i = 0; i < 48; i++) { out[48 + i] = tmp[i]; }
-	if (reset) {
-		std::memset(tmp, 0, sizeof tmp);
-		if (hipMemcpyToSymbol(HIP_SYMBOL(cvxk::g_loneStats), tmp, sizeof tmp) != hipSuccess) { return CVX_ERR_HIP; }
-	}
-	return CVX_OK;
-}
-#endif
 
 #if defined(CVX_EXPERIMENTS) || defined(CVX_PROFILE_SECTIONS) /* include/cpuvox_gpu_diag.h: not in the product library */
 int cvx_debug_occupancy(cvx_context *ctx, int64_t ldsBytes, int *blocksPerCU)

@@ -1242,6 +1242,7 @@ uint2 countInfo = uint2{ 0u, 0u }; // counting build: {RunCount | elementIndex o
 	}
 }
 
+#ifndef CVX_DEVICE_FUNCTIONS_ONLY /* cvx_lone.hip includes this header for its device functions: the kernels live in ONE translation unit (cvx_gpu.hip) */
 // ---------------------------------------------------------------------------
 // render kernel: grid = tiles, block = 64 (one wave).  LDS: words*64 uint32.
 // ---------------------------------------------------------------------------
@@ -1771,5 +1772,7 @@ __global__ void selftest_math_kernel(int op, int n, const float *__restrict__ a,
 }
 
 #endif
+
+#endif // CVX_DEVICE_FUNCTIONS_ONLY
 
 } // namespace cvxk

@@ -417,6 +417,9 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 	// A DDA walk is monotone in x and z: it leaves the world after at most dimX + dimZ columns; the cap only keeps a wave from spinning on non-finite camera data
 	int guardSteps = 2 * (dimX + dimZ + 16);
 
+#ifdef CVX_LONE_STATS
+	float lastClipBoundsMin_ = -1.0f, lastClipBoundsMax_ = -1.0f;
+#endif
 	bool alive = true; // false: the ray is finished (every exit of the reference is WriteSkybox, which the caller does)
 	while (alive) {
 		// ================= the window: the ray's next (up to) 64 columns at this level =================
@@ -527,7 +530,8 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 		runCidx[2] = runLen[0] + runLen[1];
 		RunProj P[3];
 		uint32_t faceColor[3];
-		const lanemask_t listedMask = __ballot(listed); // columns whose runs live in the run list: looked at when their turn comes (processColumn)
+		const lanemask_t listedMask = __ballot(listed);              // columns whose runs live in the run list: looked at when their turn comes (processColumn)
+		const uint32_t listedBit = listed ? 0x80000000u : 0u; // ... as bit 31 of the lane's `todo` word
 		lanemask_t topMask[3];                          // per run index: the columns whose run shows its top face (the others its bottom face, if any)
 		int runsInWindow = 1; // how many run indices the window's columns use (wave-uniform)
 #pragma unroll
@@ -558,7 +562,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 
 		CVX_LMARK("winsetup_end");
 		lanemask_t todoMask = 0ull; // the columns with any such bit, and the columns of the run list
-		uint32_t todo = 0u; // (runTests, below) which runs of the lane's column can touch the ray's state: bit 2r = the side of run r, bit 2r + 1 = its face
+		uint32_t todo = 0u; // (runTests, below) which runs of the lane's column can touch the ray's state: bit 2r = the side of run r, bit 2r + 1 = its face; bit 31: a column of the run list
 		float wbMin = 0.0f, wbMax = worldMaxY; // worldBoundsMin / Max of the lane's column (:283-284, narrowed by the cull :277-280 or set by the clip :392-393)
 
 		// ---- pixel loops (lane = pixel) ------------------------------------------------------------------------------------------------
@@ -717,7 +721,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 			}
 #endif
 			const uint32_t bits = rlu(todo, j);
-			if (CVX_RARE(((listedMask >> j) & 1ull) != 0ull)) {
+			if (CVX_RARE((int)bits < 0)) {
 				CVX_LSTAT(10);
 				// A column of the run list (cvx_device.h: a few per thousand of a built terrain, most columns of a model world such as mill.obj -- ten thin runs
 				// and more per column --, every column of a foreign blob).  Here the lanes are the column's RUNS, 64 at a time in the reference's walk order
@@ -781,6 +785,8 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 #pragma unroll
 			for (int rr = 0; rr < 3; rr++) {
 				const int r = DIR > 0 ? rr : 2 - rr; // the walk starts at the top (ITERATION_DIRECTION +1) or at the bottom (-1), :428-437
+				// (one test for a run with nothing to do, and one to leave when the runs still to come have nothing: a column with one run pays two tests, not six)
+				if ((bits & (3u << (2 * r))) == 0u) { continue; }
 				if ((bits & (1u << (2 * r))) != 0u) {
 					int rbMin = rli(P[r].rbMinS, j), rbMax = rli(P[r].rbMaxS, j);
 					if (CVX_USUAL(rbMax >= nextFreePixelMin && rbMin <= nextFreePixelMax)) { // :505
@@ -816,6 +822,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 						CVX_LSECE(6);
 					}
 				}
+				if ((DIR > 0 ? bits >> (2 * r + 2) : bits & ((1u << (2 * r)) - 1u)) == 0u) { return; }
 			}
 		};
 
@@ -830,6 +837,11 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 		auto quadSwapMax = [](float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true)); };  // quad_perm:[1,0,3,2]: min <-> max
 		auto clipColumn = [&](int j) {
 			CVX_LSTAT(11);
+#ifdef CVX_LONE_STATS
+			if (frustumBoundsMin == lastClipBoundsMin_ && frustumBoundsMax == lastClipBoundsMax_) { CVX_LSTAT(15); } // (how often a clip sees the window bounds of the clip before it)
+			lastClipBoundsMin_ = frustumBoundsMin;
+			lastClipBoundsMax_ = frustumBoundsMax;
+#endif
 			CVX_LMARK("clip_begin");
 			CVX_LSECE(3);
 			const float dL = rlf(wDistLast, j), dN = rlf(wDistNext, j);
@@ -951,7 +963,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 					faceBits[r] &= writable;
 				}
 			}
-			todo = 0u;
+			todo = listedBit;
 #pragma unroll
 			for (int r = 0; r < runs; r++) {
 				todo |= (__builtin_amdgcn_inverse_ballot_w64(sideBits[r]) ? 1u << (2 * r) : 0u) | (__builtin_amdgcn_inverse_ballot_w64(faceBits[r]) ? 2u << (2 * r) : 0u);

@@ -246,7 +246,7 @@ def test_gpu_objects_do_not_depend_on_the_build_directory(tmp_path):
         tree = tmp_path / name
         shutil.copytree(os.path.join(root, "cpuvox_amd", "csrc"), tree / "cpuvox_amd" / "csrc", ignore=shutil.ignore_patterns(".obj", "*.o", "*.so"))
         shutil.copytree(os.path.join(root, "include"), tree / "include")
-        obj = tree / "cpuvox_amd" / "csrc" / ".obj" / "cvx_shard.o"
+        obj = tree / "cpuvox_amd" / "csrc" / ".obj" / "product" / "cvx_shard.o"
         subprocess.run(["make", "-C", str(tree / "cpuvox_amd" / "csrc"), str(obj)], check=True, capture_output=True, text=True, timeout=600)
         digests.append(hashlib.sha256(obj.read_bytes()).hexdigest())
     assert digests[0] == digests[1]

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--check", type=int, default=16)
     ap.add_argument("--oracle", type=int, default=2)
     ap.add_argument("--frames-per-launch", default="")
+    ap.add_argument("--dump", default=None, help="write the per-pose wall ms of every build (best round) and the poses' ray counts to this JSON file")
     ap.add_argument("--pose-range", default=None, help="lo:hi -- only benchmark-path samples lo <= i < hi (0:450 = one clamped top / bottom segment per frame, the shape of BASELINE config 5)")
     args = ap.parse_args()
 
@@ -140,6 +141,16 @@ def main():
         worst = max(range(args.poses), key=lambda i: wall[name][best][i])
         print(f"{name:36s} {m:7.4f} {md:7.4f} {p95:7.4f} {mx:7.4f} (pose {worst}) | {km:7.4f} {kmx:7.4f}   vs first {m / base * 100 - 100:+6.2f} %", flush=True)
 
+    if args.dump:
+        import json
+
+        per_pose = {}
+        for name in names:
+            best = min(range(args.rounds), key=lambda r: statistics.mean(wall[name][r]))
+            per_pose[name] = [round(v, 5) for v in wall[name][best]]
+        rays = [sum(max(0, sg.RayCount) for sg in fr.segments) for fr in frames]
+        with open(args.dump, "w") as f:
+            json.dump({"rays": rays, "wall_ms": per_pose}, f)
     if curve:
         print("== latency curve: wall ms per blocking launch of N frames (mean over the launches of one pass over the poses, best of the rounds)")
         for b in builds:

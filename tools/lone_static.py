@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Static instruction counts of the parts of lone_kernel<false> (cvx_lone.h): compiles with -DCVX_LONE_MARK (comment markers in the assembly) and counts
+"""Static instruction counts of the parts of lone_kernel<false> (cvx_lone.h): compiles cvx_lone.hip (at its -O3, Makefile) with -DCVX_LONE_MARK (comment markers in the assembly) and counts
 the instructions between consecutive markers, per copy.  python3 tools/lone_static.py [extra hipcc flags]"""
 import os
 import re
@@ -10,8 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "cpuvox_amd", "csrc")
 out = "/tmp/lone_static.s"
 flags = ["-std=c++17", "-Os", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-mllvm", "-enable-post-misched=0", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
-         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-gpu-flush-denormals-to-zero", f"-I{ROOT}/include", f"-I{SRC}", f"-I{SRC}/host", "--cuda-device-only", "-S", "-o", out, "-DCVX_LONE_MARK"]
-subprocess.check_call(["hipcc"] + flags + sys.argv[1:] + [os.path.join(SRC, "cvx_gpu.hip")], stderr=subprocess.DEVNULL)
+         "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-gpu-flush-denormals-to-zero", f"-I{ROOT}/include", f"-I{SRC}", f"-I{SRC}/host", "--cuda-device-only", "-S", "-o", out, "-DCVX_LONE_MARK", "-O3"]
+subprocess.check_call(["hipcc"] + flags + sys.argv[1:] + [os.path.join(SRC, "cvx_lone.hip")], stderr=subprocess.DEVNULL)
 lines = open(out).read().split("\n")
 start = next(i for i, l in enumerate(lines) if l.startswith("_ZN4cvxk11lone_kernelILb0E") and ":" in l)
 end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
