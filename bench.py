@@ -686,7 +686,7 @@ def main():
             dt2 = time.perf_counter() - t0
             ctx.set_stream(None)
             # ... the same blocking calls pinned to the batch kernel (what rounds 1-5 ran a single frame on), and the curve: ms per blocking launch of n frames
-            # with the library's own kernel choice (the latency kernel up to 8192 rays per launch, the batch kernel beyond)
+            # with the library's own kernel choice (the latency kernel up to 12288 rays per launch, the batch kernel beyond)
             ctx.set_latency_kernel(gpu.LATENCY_NEVER)
             t0 = time.perf_counter()
             for k in range(K):

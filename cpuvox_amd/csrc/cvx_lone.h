@@ -435,13 +435,21 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 		{
 			CVX_LMARK("dda_begin");
 			CVX_LSEC(1);
+			// The two chains, one addition per step and chain for the whole wave: `v_add_f32 wave_shr:1` gives lane n the sum of lane n - 1's value and tDelta
+			// (lane 0, without a source lane, keeps its value), so after step s lane n holds tMax + min(n, s) additions of tDelta -- the reference's own
+			// sequence of rounded sums.  (Written as lane >= k ? X + tDelta : X the compiler keeps the 63 lane masks in scalar registers for the whole ray:
+			// 126 of them, spilled, two restores per step.)  A DPP operand needs two wait states after the vector write of its register: the other chain's
+			// addition and one s_nop are in between.
 			float X = ray.tMaxX, Z = ray.tMaxZ;
-#pragma unroll
-			for (int k = 1; k < CVX_WAVE; k++) {
-				const bool further = lane >= k;
-				const float nx_ = X + ray.tDeltaX, nz_ = Z + ray.tDeltaZ;
-				X = further ? nx_ : X;
-				Z = further ? nz_ : Z;
+			{
+				const float stepX = ray.tDeltaX, stepZ = ray.tDeltaZ;
+#define CVX_CHAIN_STEP "v_add_f32_dpp %0, %0, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
+#define CVX_CHAIN_STEPS_7 CVX_CHAIN_STEP CVX_CHAIN_STEP CVX_CHAIN_STEP CVX_CHAIN_STEP CVX_CHAIN_STEP CVX_CHAIN_STEP CVX_CHAIN_STEP
+				asm("s_nop 1\n\t" CVX_CHAIN_STEPS_7 CVX_CHAIN_STEPS_7 CVX_CHAIN_STEPS_7 CVX_CHAIN_STEPS_7 CVX_CHAIN_STEPS_7 CVX_CHAIN_STEPS_7 CVX_CHAIN_STEPS_7 CVX_CHAIN_STEPS_7 CVX_CHAIN_STEPS_7
+				    : "+v"(X), "+v"(Z)
+				    : "v"(stepX), "v"(stepZ));
+#undef CVX_CHAIN_STEPS_7
+#undef CVX_CHAIN_STEP
 			}
 			// rank of X[lane] = lane + #{m : Z[m] <= X[lane]}; rank of Z[lane] = lane + #{n : X[n] < Z[lane]}
 			int belowX = 0, belowZ = 0;

@@ -161,7 +161,7 @@ int cvx_set_shard(cvx_context *ctx, int shardIndex, int shardCount);
 /* Which kernel a draw goes to.  The reference's caller issues ONE blocking DrawSegments per frame (UnityManager.cs:182, RenderManager.cs:358-363): a
  * few thousand rays, far too few for the batch kernel (one lane per ray).  Such launches go to the latency kernel (one wavefront per RAY, its lanes the
  * ray's next 64 columns: csrc/cvx_lone.h); large batches go to the batch kernel.  Same raybuffers bit for bit either way.
- *   CVX_LATENCY_AUTO (default): the latency kernel for launches of at most ~8192 rays whose pixel windows fit its mask (4096 pixels),
+ *   CVX_LATENCY_AUTO (default): the latency kernel for launches of at most ~12 000 rays (~8000 at 4K) whose pixel windows fit its mask (4096 pixels),
  *   CVX_LATENCY_NEVER / CVX_LATENCY_ALWAYS: pin the choice (ALWAYS still falls back to the batch kernel for windows of more than 4096 pixels and while the
  *   work counters are enabled: the counting variant exists for the batch kernel only). */
 enum { CVX_LATENCY_AUTO = 0, CVX_LATENCY_NEVER = 1, CVX_LATENCY_ALWAYS = 2 };
