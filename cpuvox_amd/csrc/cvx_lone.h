@@ -906,7 +906,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 				CVX_LSECE(4);
 				const float mine = ptX / ptZ; // lanes: minLast, maxLast, minNext, maxNext
 				const float partner = quadSwapMax(mine);
-				const bool sw = roleMax ? mine < partner : partner < mine; // :339-346: max < min -> swap
+				const bool sw = __builtin_amdgcn_inverse_ballot_w64((roleMaxBits & __ballot(mine < partner)) | (~roleMaxBits & __ballot(partner < mine))); // :339-346: max < min -> swap
 				const float v = sw ? partner : mine;
 				const float o = quadSwapNext(v);
 				const float lastV = roleNext ? o : v, nextV = roleNext ? v : o;
