@@ -7,8 +7,8 @@
 //
 // Here the 64 lanes of a wave hold 64 CONSECUTIVE COLUMNS of one ray (a "window"), and everything of ExecuteRay (DrawSegmentRayJob.cs:195-620) that
 // does not depend on the ray's evolving pixel state is computed for the whole window at once:
-//   * the DDA sequence (SegmentDDAData.Step, SegmentDDAData.cs:135-150): the wave runs the ray's DDA 64 steps ahead (the reference's own additions in
-//     the reference's own order: wave-uniform), lane k latches the state of step k;
+//   * the DDA sequence (SegmentDDAData.Step, SegmentDDAData.cs:135-150): the crossings of the x planes and of the z planes are two chains of the reference's
+//     own additions (lane n holds the n-th sum of each: 63 DPP wave-shift additions per chain), merged by rank (7 ds_bpermute steps); lane k gets column k;
 //   * the 64 column records of the window: ONE round trip to memory instead of one per column;
 //   * the Q corners (:289-293) and, for each of the up to three solid runs a record holds, the whole side / face projection (:478-502, :566-578): near
 //     clip, the six quotients, the rounded pixel bounds and the texture generators -- pure functions of the column's two distances and the run's span;
@@ -19,11 +19,13 @@
 //     (:461-475, :505, :581) are evaluated for ALL remaining columns of the window in one pass; a ballot + s_ff1 finds the first column that can
 //     touch the state; the columns before it provably change nothing (they are culled, or none of their runs overlaps [nextFreePixelMin, Max]);
 //   * that column is processed exactly as the reference does, run by run, with wave-uniform scalars read from its lane (v_readlane);
-//   * after a pixel write the directions are invalid (:522,598): the next non-empty column clips (:295-422) -- computed in the column's own lane --
-//     and the pass over the remaining columns is repeated with the new directions.
+//   * after a pixel write the directions are invalid (:522,598): the next non-empty column clips (:295-422) -- its four division chains in the four lanes
+//     of a quad -- and the pass over the remaining columns is repeated with the new directions.
+// Boolean algebra of the pass and the clip is written on BALLOTS (64-bit scalars): selects and merges of per-lane booleans would be made in vector registers.
 // The seen mask (:208) is ONE WORD PER LANE in a vector register (two for windows of more than 2048 pixels): horizon scans (:407-414, :678-692) are a
-// ballot over "my word has an unseen bit in range" + s_ff1 / s_flbit + one v_readlane; the pixel loops (:519-533, :595-603) run with lane = PIXEL (64
-// pixels per trip); the mask clear is free and the skybox pass (:699-716) is lane = word.
+// ballot over "my word has an unseen bit in range" + s_ff1 / s_flbit + one v_readlane (first: one look at the word the scan usually ends in); the pixel
+// loops (:519-533, :595-603) run with lane = PIXEL; a range inside one mask word (the usual few pixels) takes its word out with v_readlane and puts it back
+// with v_writelane; the mask clear is free and the skybox is the initial value of the ray's pixel row in LDS (written out once, at the end).
 //
 // Arithmetic: the SAME device functions as render_kernel (cvx_kernels.h) on the same values in the same order -- the contract (IEEE binary32, no
 // contraction, x86 cvttss2si) is shared; results are bit-identical to render_kernel and to the CPU oracle (tests/test_gpu_parity.py, tools/soak.py).
@@ -574,7 +576,6 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 		float wbMin = 0.0f, wbMax = worldMaxY; // worldBoundsMin / Max of the lane's column (:283-284, narrowed by the cull :277-280 or set by the clip :392-393)
 
 		// ---- pixel loops (lane = pixel) ------------------------------------------------------------------------------------------------
-		// side of a run, :519-533: the unseen pixels of [rbMin, rbMax] get the run's perspective-correct colour
 		// A pixel range inside ONE mask word (the usual case: a few pixels): the word comes out of its lane once (v_readlane), gives the unseen pixels of the
 		// range, and goes back with the range marked (v_writelane) -- no pass over the 64 words.  Returns false when the range spans words (the general loops).
 		auto oneWordRange = [&](int rbMin, int rbMax, lanemask_t &unseen) -> bool {
@@ -593,6 +594,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 			}
 			return true;
 		};
+		// side of a run, :519-533: the unseen pixels of [rbMin, rbMax] get the run's perspective-correct colour
 		// (`operands` delivers the side's wave-uniform values -- v_readlanes of the column's lane -- and is only asked when a pixel is there to be written: more
 		// than a third of the sides that reach this point hold no unseen pixel)
 		struct SideOperands {
