@@ -108,8 +108,8 @@ struct cvx_context {
 #define CVX_LONE_DEFAULT_MODE 1
 #endif
 	int loneMode = CVX_LONE_DEFAULT_MODE; // 1: lone_kernel for launches of at most loneWaveBudget rays; 0 never, 2 always (experiment build: CVX_LONE=0 / 1; variants: -DCVX_LONE_DEFAULT_MODE)
-	int loneWaveBudget = 12288;      // rays (= waves, tiles x 64) up to which a launch goes to lone_kernel (budget sweep 8192 ... 16384 over launches of 2 - 6 frames,
-	                                 // profiles/r06_latency.md); two thirds of it for windows of more than 2048 pixels (4K: the two-register instance, 12 000-ray frames lose there)
+	int loneWaveBudget = 12288;      // AUTO: launches of up to this many rays (= waves, tiles x 64) go to lone_kernel: 2 - 3 frames at 1080p; three quarters of it above
+	                                 // 2560 x 1440 (4K: frames of up to ~9 000 rays).  Budget sweep over launches of 2 - 6 frames, per-pose crossover at 4K: profiles/r06_latency.md
 
 	int shardIndex = 0, shardCount = 1;
 	bool countersEnabled = false;

@@ -765,7 +765,10 @@ int DrawBatch(cvx_context *ctx, int frameCount, const cvx_segment_data *segments
 		// A launch of few rays (the reference's call pattern: ONE frame per blocking call, RenderManager.cs:358-363) goes to the latency kernel
 		// (cvx_lone.h): one wave per RAY, its lanes the ray's next 64 columns.  Its mask lives in one or two vector registers: windows of up to 4096 pixels.
 		ctx->launchLone = 0;
-		if (!ctx->countersEnabled && ctx->maskWordsNeeded <= 2 * CVX_WAVE && (ctx->loneMode == 2 || (ctx->loneMode == 1 && n * (size_t)CVX_WAVE <= (size_t)(ctx->maskWordsNeeded > CVX_WAVE ? ctx->loneWaveBudget * 2 / 3 : ctx->loneWaveBudget))) && n > 0) {
+		// AUTO's budget is in rays (= waves).  The crossover against the batch kernel is at ~12 000 - 14 000 rays at 1080p (2 - 3 frames) and between 8 000 and
+		// 11 000 at 4K, where a ray has twice the pixels to write and so twice the events (budget sweep and per-pose crossover: profiles/r06_latency.md)
+		const size_t loneBudget = (long long)ctx->resX * ctx->resY > 2560ll * 1440ll ? (size_t)ctx->loneWaveBudget * 3 / 4 : (size_t)ctx->loneWaveBudget;
+		if (!ctx->countersEnabled && ctx->maskWordsNeeded <= 2 * CVX_WAVE && (ctx->loneMode == 2 || (ctx->loneMode == 1 && n * (size_t)CVX_WAVE <= loneBudget)) && n > 0) {
 			// (one workgroup per RAY: the kernel takes tile blockIdx / 64, ray blockIdx % 64 of it -- the tile list goes to the device as it is, longest tiles first)
 			std::vector<DevTile> sortedTiles;
 			sortedTiles.reserve(n);

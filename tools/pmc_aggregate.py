@@ -18,7 +18,7 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL_SOURCES = ["cvx_kernels.h", "cvx_lone.h", "cvx_device.h", "cvx_context.h", "cvx_downsample.h", "cvx_gpu.hip", "cvx_world.hip", "cvx_shard.hip", "Makefile"]
+KERNEL_SOURCES = ["cvx_kernels.h", "cvx_lone.h", "cvx_lone.hip", "cvx_device.h", "cvx_context.h", "cvx_downsample.h", "cvx_gpu.hip", "cvx_world.hip", "cvx_shard.hip", "Makefile"]
 
 
 def kernel_sources_sha256() -> str:
