@@ -931,14 +931,11 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 
 		// ---- one pass over the lanes >= from with the ray's current state: the cull of every column (:261-281) and whether any of its runs can touch
 		// the state (:461-475, :505, :549-565, :581).  `clipped` >= 0: that lane's column was just clipped (it is drawn with the clip's world bounds).
-		// which runs of the lane's column can touch the ray's state, given the column's world bounds (wbMin / wbMax) and the current window: bit 2r = the side
-		// of run r, bit 2r + 1 = its face, bit 31 = a column of the run list (looked at when its turn comes)
-		// which runs of the lane's column can touch the ray's state, given the column's world bounds (wbMin / wbMax) and the current window: bit 2r = the side
-		// of run r, bit 2r + 1 = its face, bit 31 = a column of the run list (looked at when its turn comes).
-		// A run's side / face has to overlap the window (:505 / :581) and to hold an unseen pixel (windowIsClean / mayHoldUnseen above: one test for the run's
-		// side and face together).
-		// (the gathers of all runs are issued before the first is looked at: one LDS round trip per pass, not one per run)
-		// (the boolean algebra is written on the ballots -- 64-bit scalars --: selects and merges of per-lane booleans would be made in vector registers)
+		// runTests: which runs of the lane's column can touch the ray's state, given the column's world bounds (wbMin / wbMax) and the current window -- `todo`:
+		// bit 2r = the side of run r, bit 2r + 1 = its face, bit 31 = a column of the run list (looked at when its turn comes).
+		// A run's side / face has to overlap the window (:505 / :581) and to hold an unseen pixel (windowIsClean / holdsUnseen above: one test for the run's
+		// side and face together; the gathers of all runs are issued before the first is looked at: one LDS round trip per pass, not one per run).
+		// The boolean algebra is written on the ballots -- 64-bit scalars --: selects and merges of per-lane booleans would be made in vector registers.
 		auto runTestsOf = [&](auto runsConstant) {
 			constexpr int runs = decltype(runsConstant)::value;
 			const bool windowClean = windowIsClean();
