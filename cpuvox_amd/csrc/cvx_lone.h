@@ -991,6 +991,9 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 		lanemask_t hits = 0ull, leftWorldMask = 0ull;
 		auto cullAndFilter = [&](int from, int clipped) {
 			CVX_LSTAT(14);
+#ifdef CVX_LONE_STATS
+			if (runsInWindow >= 2) { CVX_LSTAT(24); if ((__ballot(code >= 2) & lanes_from(from)) == 0ull) { CVX_LSTAT(25); } } // (passes over two-run windows / ... whose remaining columns have one run)
+#endif
 			CVX_LMARK("filter_begin");
 			CVX_LSECE(5);
 			const float columnWorldMin = (float)(rec.y & 0xFFFFu);
