@@ -88,6 +88,22 @@ __device__ __forceinline__ lanemask_t lanes_from(int l) { return ~0ull << l; } /
 __device__ __forceinline__ float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// The DDA's two crossing chains (lone_trace_ray), one addition per step and chain for the whole wave: `v_add_f32 wave_shr:1` gives lane n the sum of lane n - 1's
+// value and the step (lane 0, without a source lane, keeps its value), so after step s lane n holds its start value + min(n, s) additions of the step -- the
+// reference's own sequence of rounded sums (SegmentDDAData.Step, SegmentDDAData.cs:135-150).  Called with X = tMax.x, Z = tMax.y in every lane.  (Written as
+// lane >= k ? X + step : X the compiler keeps the 63 lane masks in scalar registers for the whole ray: 126 of them, spilled, two restores per step.)  A DPP
+// operand needs two wait states after the vector write of its register: the other chain's addition and one s_nop are in between.  Needs all 64 lanes active.
+__device__ __forceinline__ void lone_crossing_chains(float &X, float &Z, float stepX, float stepZ)
+{
+#define CVX_CHAIN_STEP "v_add_f32_dpp %0, %0, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
+#define CVX_CHAIN_STEPS_7 CVX_CHAIN_STEP CVX_CHAIN_STEP CVX_CHAIN_STEP CVX_CHAIN_STEP CVX_CHAIN_STEP CVX_CHAIN_STEP CVX_CHAIN_STEP
+	asm("s_nop 1\n\t" CVX_CHAIN_STEPS_7 CVX_CHAIN_STEPS_7 CVX_CHAIN_STEPS_7 CVX_CHAIN_STEPS_7 CVX_CHAIN_STEPS_7 CVX_CHAIN_STEPS_7 CVX_CHAIN_STEPS_7 CVX_CHAIN_STEPS_7 CVX_CHAIN_STEPS_7
+	    : "+v"(X), "+v"(Z)
+	    : "v"(stepX), "v"(stepZ));
+#undef CVX_CHAIN_STEPS_7
+#undef CVX_CHAIN_STEP
+}
+
 // bits of mask word `w` (absolute word index) that fall inside the pixel range [lo, hi]; any w, lo, hi (empty ranges give 0)
 __device__ __forceinline__ uint32_t range_mask_any(int w, int lo, int hi)
 {
@@ -437,22 +453,8 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 		{
 			CVX_LMARK("dda_begin");
 			CVX_LSEC(1);
-			// The two chains, one addition per step and chain for the whole wave: `v_add_f32 wave_shr:1` gives lane n the sum of lane n - 1's value and tDelta
-			// (lane 0, without a source lane, keeps its value), so after step s lane n holds tMax + min(n, s) additions of tDelta -- the reference's own
-			// sequence of rounded sums.  (Written as lane >= k ? X + tDelta : X the compiler keeps the 63 lane masks in scalar registers for the whole ray:
-			// 126 of them, spilled, two restores per step.)  A DPP operand needs two wait states after the vector write of its register: the other chain's
-			// addition and one s_nop are in between.
 			float X = ray.tMaxX, Z = ray.tMaxZ;
-			{
-				const float stepX = ray.tDeltaX, stepZ = ray.tDeltaZ;
-#define CVX_CHAIN_STEP "v_add_f32_dpp %0, %0, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
-#define CVX_CHAIN_STEPS_7 CVX_CHAIN_STEP CVX_CHAIN_STEP CVX_CHAIN_STEP CVX_CHAIN_STEP CVX_CHAIN_STEP CVX_CHAIN_STEP CVX_CHAIN_STEP
-				asm("s_nop 1\n\t" CVX_CHAIN_STEPS_7 CVX_CHAIN_STEPS_7 CVX_CHAIN_STEPS_7 CVX_CHAIN_STEPS_7 CVX_CHAIN_STEPS_7 CVX_CHAIN_STEPS_7 CVX_CHAIN_STEPS_7 CVX_CHAIN_STEPS_7 CVX_CHAIN_STEPS_7
-				    : "+v"(X), "+v"(Z)
-				    : "v"(stepX), "v"(stepZ));
-#undef CVX_CHAIN_STEPS_7
-#undef CVX_CHAIN_STEP
-			}
+			lone_crossing_chains(X, Z, ray.tDeltaX, ray.tDeltaZ);
 			// rank of X[lane] = lane + #{m : Z[m] <= X[lane]}; rank of Z[lane] = lane + #{n : X[n] < Z[lane]}
 			int belowX = 0, belowZ = 0;
 #pragma unroll

@@ -37,7 +37,7 @@ EXPORTS = [
     "cvx_image_plan_tile_out", "cvx_image_pack", "cvx_image_exchange", "cvx_image_unpack",
 ]
 # include/cpuvox_gpu_diag.h: only the experiment / profiling builds export these (cpuvox_amd.gpu.use_library(".../libcpuvox_gpu_exp.so"))
-DIAG_EXPORTS = ["cvx_selftest_math", "cvx_selftest_scan", "cvx_debug_occupancy", "cvx_debug_section_cycles", "cvx_debug_section_histogram"]
+DIAG_EXPORTS = ["cvx_selftest_math", "cvx_selftest_scan", "cvx_selftest_lone", "cvx_debug_occupancy", "cvx_debug_section_cycles", "cvx_debug_section_histogram"]
 
 
 class Counters(C.Structure):
@@ -138,6 +138,7 @@ def _bind(path: str) -> C.CDLL:
             L.cvx_debug_occupancy.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int)]
             L.cvx_selftest_math.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
             L.cvx_selftest_scan.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_uint64)]
+            L.cvx_selftest_lone.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.cvx_world_downsample.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_float)]
         L.cvx_world_build_lods.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -402,6 +403,15 @@ class Context:
         b = np.ascontiguousarray(b, dtype=np.float32)
         out = np.empty_like(a)
         self._check(self._diag("cvx_selftest_math")(self._h, op, a.size, a.ctypes.data, b.ctypes.data, out.ctypes.data))
+        return out
+
+    def selftest_lone(self, op: int, a: np.ndarray, b: np.ndarray) -> np.ndarray:
+        """The latency kernel's inline-assembly primitives on the caller's values (diagnostics build): op 0 the crossing chains, op 1 v_writelane."""
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        b = np.ascontiguousarray(b, dtype=np.float32)
+        waves = b.size
+        out = np.empty(waves * (128 if op == 0 else 64), dtype=np.float32)
+        self._check(self._diag("cvx_selftest_lone")(self._h, op, waves, a.ctypes.data, b.ctypes.data, out.ctypes.data))
         return out
 
     def selftest_scan(self, values: np.ndarray):

@@ -32,6 +32,11 @@ int cvx_selftest_math(cvx_context *ctx, int op, int n, const float *a, const flo
  * replaced by their exclusive prefix sums (modulo 2^32), *total receives the 64-bit sum.  For tests of the tail / multi-chunk paths. */
 int cvx_selftest_scan(cvx_context *ctx, int n, uint32_t *values, uint64_t *total);
 
+/* The two inline-assembly primitives of the latency kernel (csrc/cvx_lone.h) on a caller's values, one wavefront per case:
+ * op 0: the DDA's crossing chains -- out[128 w + n] = a[w] + n additions of b[w], out[128 w + 64 + n] = a[w] + n additions of -b[w] (n = 0 .. 63; a, b: `waves` floats);
+ * op 1: v_writelane -- out[64 w + n] = a[64 w + n], except out[64 w + (w % 64)] = b[w] (a: 64 x waves floats, b: waves). */
+int cvx_selftest_lone(cvx_context *ctx, int op, int waves, const float *a, const float *b, float *out);
+
 #ifdef __cplusplus
 }
 #endif

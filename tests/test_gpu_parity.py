@@ -603,6 +603,35 @@ def test_short_division_is_ieee_division(diag_context):
         assert np.array_equal(ctx.selftest_math(15, a, b) == 1.0, (mag >= np.float32(2.0 ** -30)) & (mag <= np.float32(2.0 ** 30)))
 
 
+def test_latency_kernel_assembly_primitives(diag_context):
+    """The two inline-assembly pieces of the latency kernel (csrc/cvx_lone.h) on their own, one wavefront per case:
+    the DDA's crossing chains -- 63 `v_add_f32 wave_shr:1` per chain, lane n = n of the reference's rounded additions (SegmentDDAData.cs:135-150) --
+    against the additions done one after the other in binary32, and `v_writelane` with its lane select in M0 against an array assignment.  The
+    scenes cover both through the raybuffers; here the wait states the compiler cannot see are pinned by themselves."""
+    ctx = diag_context
+    rng = np.random.default_rng(11)
+    waves = 4096
+    start = (rng.random(waves, dtype=np.float32) * np.float32(10.0) ** rng.integers(-6, 6, waves).astype(np.float32)).astype(np.float32)
+    step = (rng.random(waves, dtype=np.float32) * np.float32(10.0) ** rng.integers(-7, 7, waves).astype(np.float32) + np.float32(1e-7)).astype(np.float32)
+    start[:4] = np.array([0.0, 1.4e-45, 3.0e38, 0.33333334], dtype=np.float32)   # zero, a denormal, near overflow, an ordinary fraction
+    step[:4] = np.array([1.4e-45, 1.4e-45, 3.0e37, 10000000.0], dtype=np.float32)  # (step 1 / 1e-7: the DDA's largest tDelta)
+    got = ctx.selftest_lone(0, start, step).reshape(waves, 2, 64)
+    want = np.empty_like(got)
+    x, z = start.copy(), start.copy()
+    with np.errstate(over="ignore"):
+        for n in range(64):
+            want[:, 0, n], want[:, 1, n] = x, z
+            x = (x + step).astype(np.float32)
+            z = (z - step).astype(np.float32)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    lanes = rng.standard_normal(waves * 64).astype(np.float32)
+    values = rng.standard_normal(waves).astype(np.float32)
+    got = ctx.selftest_lone(1, lanes, values).reshape(waves, 64)
+    want = lanes.reshape(waves, 64).copy()
+    want[np.arange(waves), np.arange(waves) % 64] = values
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
 def test_cheap_texture_row_is_certified(diag_context):
     """Round 5: the side pixels take their texture row from a cheap computation (hardware reciprocals, fused multiply-adds) wherever a bound on its
     distance from the reference's value proves the floor equal (`tex_row_cheap`, cvx_kernels.h); the others take the reference's two IEEE divisions.
