@@ -995,6 +995,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 			CVX_LSTAT(14);
 #ifdef CVX_LONE_STATS
 			if (runsInWindow >= 2) { CVX_LSTAT(24); if ((__ballot(code >= 2) & lanes_from(from)) == 0ull) { CVX_LSTAT(25); } } // (passes over two-run windows / ... whose remaining columns have one run)
+			if (runsInWindow >= 3) { CVX_LSTAT(26); if ((__ballot(code >= 3) & lanes_from(from)) == 0ull) { CVX_LSTAT(27); } } // (... three-run windows / ... whose remaining columns have at most two)
 #endif
 			CVX_LMARK("filter_begin");
 			CVX_LSECE(5);
