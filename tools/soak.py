@@ -1,7 +1,8 @@
 """Parity soak (not part of the test-suite): many random camera poses, GPU raybuffers and counters against the CPU oracle.
 Usage: python tools/soak.py [poses per case]   random poses over four worlds: the counting build, then the shipped build pinned to the batch kernel AND
                                                   to the latency kernel (cvx_set_latency_kernel), each against the oracle
-       python tools/soak.py bench                 the 1000 benchmark poses as batches (batch kernel) and as single blocking draws (latency kernel)"""
+       python tools/soak.py bench                 the 1000 benchmark poses as batches (batch kernel) and as single blocking draws (latency kernel)
+       python tools/soak.py 4k [poses per case]   the same random poses at 3840x2160 and 4096x2304: windows of more than 2048 pixels, the latency kernel's two-register instance"""
 import os
 import sys
 
@@ -13,7 +14,8 @@ import oraclelib as O  # noqa: E402
 import scenes  # noqa: E402
 from cpuvox_amd import gpu  # noqa: E402
 
-poses = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1] != "bench" else 100
+big = len(sys.argv) > 1 and sys.argv[1] == "4k"
+poses = int(sys.argv[2]) if big and len(sys.argv) > 2 else (300 if big else (int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1] != "bench" else 100))
 if len(sys.argv) > 1 and sys.argv[1] == "bench":
     # every pose of the benchmark path (the 1000 samples bench.py cycles through) on the benchmark world at the benchmark resolution, as ONE
     # batch per 100 poses through the rendering build (what bench.py times) -- raybuffers against the oracle
@@ -58,7 +60,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "bench":
 CLEAR = 0x9314FFFF
 rng = np.random.default_rng(20261003)
 bad = total = 0
-for world, W, H, lod_error in (("proc1024", 1920, 1080, 1.0), ("proc512", 1280, 720, 6.0), ("mill512", 1024, 768, 1.0), ("proc256x1024x512", 801, 603, 3.0)):
+CASES = (("proc1024", 3840, 2160, 1.0), ("mill512", 4096, 2304, 2.0)) if big else (("proc1024", 1920, 1080, 1.0), ("proc512", 1280, 720, 6.0), ("mill512", 1024, 768, 1.0), ("proc256x1024x512", 801, 603, 3.0))
+for world, W, H, lod_error in CASES:
     ws = scenes.load_world(world)
     ctx = gpu.Context(0, buffer_count=4)
     ctx.upload_world(ws)
@@ -89,7 +92,7 @@ for world, W, H, lod_error in (("proc1024", 1920, 1080, 1.0), ("proc512", 1280, 
             ok = ok and np.array_equal(r_td[:n_td], o_td[:n_td]) and np.array_equal(r_lr[:n_lr], o_lr[:n_lr])
         ctx.set_latency_kernel(gpu.LATENCY_AUTO)
         total += 1
-        if (i + 1) % 1000 == 0:
+        if (i + 1) % (100 if big else 1000) == 0:
             print(f"  {world}: {i + 1} poses, {bad} mismatches so far", flush=True)
         if not ok:
             bad += 1
