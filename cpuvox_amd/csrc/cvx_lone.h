@@ -657,43 +657,6 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 			}
 			lone_mark<HI>(seen, rbMin, rbMax);
 		};
-		// one solid run of the column being processed (every operand wave-uniform): :461-475 were tested by the caller; side :484-542, face :544-610
-		auto drawRun = [&](const RunProj &R, float elementBoundsMin, float elementBoundsMax, int elementLength, int elementColorsIndex, uint32_t columnColorsOff, uint32_t secondaryColor,
-		                   float worldBoundsMin, float worldBoundsMax) {
-			if (R.sideVisible) {
-				int rbMin = R.rbMinS, rbMax = R.rbMaxS;
-				if (rbMax >= nextFreePixelMin && rbMin <= nextFreePixelMax) { // :505
-					CVX_LSTAT(7);
-					CVX_LMARK("sidereduce_begin");
-					CVX_LSECE(7);
-					lone_reduce_pixel_horizon<HI>(seen, omin, omax, rbMin, rbMax, nextFreePixelMin, nextFreePixelMax, frustumBoundsMin, frustumBoundsMax);
-					CVX_LMARK("sidereduce_end");
-					CVX_LSECE(8);
-					if (rbMin <= rbMax) {
-						sidePixels(rbMin, rbMax, [&]() { return SideOperands{ R.boundsX, R.boundsY, R.uvAx, R.uvBx, R.uvAy, R.uvBy, elementLength, elementColorsIndex, columnColorsOff }; });
-					}
-					if (nextFreePixelMin > nextFreePixelMax) { alive = false; return; } // :535-539
-					CVX_LMARK("sidepixels_end");
-					CVX_LSECE(6);
-				}
-			}
-			const bool faceWanted = (R.faceTop && !(elementBoundsMax > worldBoundsMax)) || (R.faceBottom && !(elementBoundsMin < worldBoundsMin)); // :549-565
-			if (faceWanted && R.faceNear) {
-				int rbMin = R.rbMinF, rbMax = R.rbMaxF;
-				if (rbMax >= nextFreePixelMin && rbMin <= nextFreePixelMax) { // :581
-					CVX_LSTAT(8);
-					CVX_LMARK("facereduce_begin");
-					CVX_LSECE(9);
-					lone_reduce_pixel_horizon<HI>(seen, omin, omax, rbMin, rbMax, nextFreePixelMin, nextFreePixelMax, frustumBoundsMin, frustumBoundsMax);
-					CVX_LMARK("facereduce_end");
-					CVX_LSECE(10);
-					if (rbMin <= rbMax) { facePixels(rbMin, rbMax, secondaryColor); }
-					if (nextFreePixelMin > nextFreePixelMax) { alive = false; return; } // :604-608
-					CVX_LMARK("facepixels_end");
-					CVX_LSECE(6);
-				}
-			}
-		};
 
 		// Can a pixel range change the ray's state?  It has to overlap the window [nextFreePixelMin, Max] (:505 / :581) -- and to hold an UNSEEN pixel:
 		// ReducePixelHorizon (:660-697) moves a bound only when the range covers it (and the bounds are unseen pixels), the pixel loops only write unseen
@@ -719,7 +682,6 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 			const int more = min(hi - lo, 31 - first); // pixels of the range in this word, less one
 			return __ballot((hi - lo) > more) | __ballot(((~word >> first) << (31 - more)) != 0u);
 		};
-		auto mayHoldUnseen = [&](int lo, int hi) -> bool { return __builtin_amdgcn_inverse_ballot_w64(holdsUnseen(gatherWord(lo), lo, hi)); };
 
 		// ---- element loop (:424-611) of column j, run by run in the reference's walk order, with the ray's current state
 		auto processColumn = [&](int j) {
@@ -738,7 +700,7 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 				// A column of the run list (cvx_device.h: a few per thousand of a built terrain, most columns of a model world such as mill.obj -- ten thin runs
 				// and more per column --, every column of a foreign blob).  Here the lanes are the column's RUNS, 64 at a time in the reference's walk order
 				// (:428-437): one load brings them all, one pass projects them all (project_run with the column's corners, wave-uniform, and a run per lane),
-				// one more fetches their face colours; then the runs that can touch the state take their turn one after the other (drawRun with the lane's values).
+				// one more fetches their face colours; then the runs that can touch the state take their turn one after the other, their operands read from their lanes.
 				const float worldBoundsMin = rlf(wbMin, j), worldBoundsMax = rlf(wbMax, j);
 				const uint32_t columnColorsOff = L.elementsOff + (rlu(rec.x, j) & 0x3FFFFFFFu) * 4u;
 				const uint32_t columnRunsOff = L.runsOff + rlu(rec.z, j) * 8u;
@@ -759,34 +721,45 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 					uint32_t secondaryColor = 0u;
 					if (in) { secondaryColor = ld_color(arena, columnColorsOff + ((uint32_t)(R.faceTop ? elementColorsIndex : elementColorsIndex + elementLength - 1) << L.colorShift)); }
 					const int loS = max(R.rbMinS, nextFreePixelMin), hiS = min(R.rbMaxS, nextFreePixelMax), loF = max(R.rbMinF, nextFreePixelMin), hiF = min(R.rbMaxF, nextFreePixelMax);
-					const bool side = ((int)in & (int)R.sideVisible & (int)(loS <= hiS)) != 0;
-					const bool wanted = (((int)R.faceTop & (int)!(elementBoundsMax > worldBoundsMax)) | ((int)R.faceBottom & (int)!(elementBoundsMin < worldBoundsMin))) != 0;
-					const bool face = ((int)in & (int)wanted & (int)R.faceNear & (int)(loF <= hiF)) != 0;
-					const uint32_t runFlags = (R.sideVisible ? 1u : 0u) | (R.faceNear ? 2u : 0u) | (R.faceTop ? 4u : 0u) | (R.faceBottom ? 8u : 0u);
-					bool writable = true;
-					if (!windowIsClean()) { writable = mayHoldUnseen(side ? (face ? min(loS, loF) : loS) : loF, side ? (face ? max(hiS, hiF) : hiS) : hiF); }
-					lanemask_t candidates = __ballot((side || face) && writable);
+					// (on ballots, as in the pass) the run's side / face can touch the state: inside the world bounds (:461-475), visible (:484 / :566), wanted (:549-565),
+					// overlapping the window (:505 / :581) -- and holding an unseen pixel, side and face each by its own test: three quarters of a model world's
+					// candidates hold one in one of the two only
+					const lanemask_t inBits = __ballot(in);
+					lanemask_t sideBits = inBits & __ballot(R.sideVisible) & __ballot(loS <= hiS);
+					const lanemask_t wantedBits = (__ballot(R.faceTop) & __ballot(!(elementBoundsMax > worldBoundsMax))) | (__ballot(R.faceBottom) & __ballot(!(elementBoundsMin < worldBoundsMin)));
+					lanemask_t faceBits = inBits & wantedBits & __ballot(R.faceNear) & __ballot(loF <= hiF);
+					if (!windowIsClean()) {
+						const uint32_t wordS = gatherWord(loS), wordF = gatherWord(loF);
+						sideBits &= holdsUnseen(wordS, loS, hiS);
+						faceBits &= holdsUnseen(wordF, loF, hiF);
+					}
+					lanemask_t candidates = sideBits | faceBits;
+					// the candidates take their turn in walk order, each with its operands read from its lane when (and if) they are needed
 					while (candidates != 0ull && alive) {
 						const int l = __ffsll((long long)candidates) - 1;
 						candidates &= candidates - 1ull;
-						RunProj U;
-						const uint32_t uf = rlu(runFlags, l);
-						U.sideVisible = (uf & 1u) != 0u;
-						U.faceNear = (uf & 2u) != 0u;
-						U.faceTop = (uf & 4u) != 0u;
-						U.faceBottom = (uf & 8u) != 0u;
-						U.rbMinS = rli(R.rbMinS, l);
-						U.rbMaxS = rli(R.rbMaxS, l);
-						U.rbMinF = rli(R.rbMinF, l);
-						U.rbMaxF = rli(R.rbMaxF, l);
-						U.boundsX = rlf(R.boundsX, l);
-						U.boundsY = rlf(R.boundsY, l);
-						U.uvAx = rlf(R.uvAx, l);
-						U.uvBx = rlf(R.uvBx, l);
-						U.uvAy = rlf(R.uvAy, l);
-						U.uvBy = rlf(R.uvBy, l);
-						drawRun(U, rlf(elementBoundsMin, l), rlf(elementBoundsMax, l), rli(elementLength, l), rli(elementColorsIndex, l), columnColorsOff, rlu(secondaryColor, l), worldBoundsMin,
-						        worldBoundsMax);
+						if (((sideBits >> l) & 1ull) != 0ull) { // side :484-542
+							int rbMin = rli(R.rbMinS, l), rbMax = rli(R.rbMaxS, l);
+							if (rbMax >= nextFreePixelMin && rbMin <= nextFreePixelMax) { // :505
+								CVX_LSTAT(7);
+								lone_reduce_pixel_horizon<HI>(seen, omin, omax, rbMin, rbMax, nextFreePixelMin, nextFreePixelMax, frustumBoundsMin, frustumBoundsMax);
+								if (rbMin <= rbMax) {
+									sidePixels(rbMin, rbMax, [&]() {
+										return SideOperands{ rlf(R.boundsX, l), rlf(R.boundsY, l), rlf(R.uvAx, l), rlf(R.uvBx, l), rlf(R.uvAy, l), rlf(R.uvBy, l), rli(elementLength, l), rli(elementColorsIndex, l), columnColorsOff };
+									});
+								}
+								if (nextFreePixelMin > nextFreePixelMax) { alive = false; return; } // :535-539
+							}
+						}
+						if (((faceBits >> l) & 1ull) != 0ull) { // face :544-610
+							int rbMin = rli(R.rbMinF, l), rbMax = rli(R.rbMaxF, l);
+							if (rbMax >= nextFreePixelMin && rbMin <= nextFreePixelMax) { // :581
+								CVX_LSTAT(8);
+								lone_reduce_pixel_horizon<HI>(seen, omin, omax, rbMin, rbMax, nextFreePixelMin, nextFreePixelMax, frustumBoundsMin, frustumBoundsMax);
+								if (rbMin <= rbMax) { facePixels(rbMin, rbMax, rlu(secondaryColor, l)); }
+								if (nextFreePixelMin > nextFreePixelMax) { alive = false; return; } // :604-608
+							}
+						}
 					}
 				}
 				return;
