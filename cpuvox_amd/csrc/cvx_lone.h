@@ -1018,6 +1018,9 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 					if ((hits >> j) & 1ull) {
 						CVX_LSTAT(21);
 						processColumn(j);
+#ifdef CVX_LONE_STATS
+						if (!directionsGone()) { CVX_LSTAT(28); }
+#endif
 						CVX_LSECE(0);
 						if (directionsGone()) { hitsValid = false; }
 					}
@@ -1042,6 +1045,9 @@ __device__ __forceinline__ void lone_trace_ray(const DevFrame &F, const DevSegme
 				const int fh = h != 0ull ? __ffsll((long long)h) - 1 : CVX_WAVE, fl = l != 0ull ? __ffsll((long long)l) - 1 : CVX_WAVE;
 				if (fl < fh) { alive = false; break; } // :265-269: the frustum left the world
 				processColumn(fh);
+#ifdef CVX_LONE_STATS
+				if (!directionsGone()) { CVX_LSTAT(28); } // (a hit of the pass that wrote no pixel)
+#endif
 				CVX_LSECE(0);
 				next = fh + 1;
 				if (directionsGone()) { hitsValid = false; } // a pixel was written: the directions are gone (:522,598)

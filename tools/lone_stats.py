@@ -45,7 +45,7 @@ ticks_per_ms = sum(l[1] for l in lives) / sum(l[0] for l in lives)  # (an upper 
 print(f"kernel {ms:.3f} ms per frame; longest wave / kernel: clock ticks per ms >= {ticks_per_ms:.0f}; sum of wave lives / (longest life x waves) = "
       f"{sum(l[2] for l in lives) / sum(l[1] * l[3] for l in lives):.3f}; columns of the longest wave ~{sum(l[4] for l in lives) / poses:.0f}")
 names = ["windows", "columns", "run projections (per window and run index)", "side trips", "side pixels", "face trips", "face pixels", "side overlaps (:505)", "face overlaps (:581)",
-         "processColumn", "... listed", "clipColumn", "... general form", "... window touched", "cullAndFilter", "... with the window bounds of the clip before it", "rays", "processColumn with a clean window", "(sum of lives)", "(longest life)", "(columns of the longest)", "clipped column is itself a hit", "-", "-", "passes over windows with a second run", "... whose remaining columns have only one", "passes over windows with a third run", "... whose remaining columns have at most two"]
+         "processColumn", "... listed", "clipColumn", "... general form", "... window touched", "cullAndFilter", "... with the window bounds of the clip before it", "rays", "processColumn with a clean window", "(sum of lives)", "(longest life)", "(columns of the longest)", "clipped column is itself a hit", "-", "-", "passes over windows with a second run", "... whose remaining columns have only one", "passes over windows with a third run", "... whose remaining columns have at most two", "hits of the pass that wrote no pixel"]
 print(f"per frame ({poses} frames {W}x{H} {world}):")
 for i, n in enumerate(names):
     print(f"  {n:50s} {out[i] / poses:12.1f}     longest wave: {longest[i] / poses:10.1f}")
