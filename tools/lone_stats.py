@@ -44,10 +44,13 @@ ms = sum(l[0] for l in lives) / poses
 ticks_per_ms = sum(l[1] for l in lives) / sum(l[0] for l in lives)  # (an upper bound of the clock: the longest wave cannot outlive the kernel)
 print(f"kernel {ms:.3f} ms per frame; longest wave / kernel: clock ticks per ms >= {ticks_per_ms:.0f}; sum of wave lives / (longest life x waves) = "
       f"{sum(l[2] for l in lives) / sum(l[1] * l[3] for l in lives):.3f}; columns of the longest wave ~{sum(l[4] for l in lives) / poses:.0f}")
+names_extra = {29: "reduces that raise nextFreePixelMin", 46: "reduces that lower nextFreePixelMax"}
 names = ["windows", "columns", "run projections (per window and run index)", "side trips", "side pixels", "face trips", "face pixels", "side overlaps (:505)", "face overlaps (:581)",
          "processColumn", "... listed", "clipColumn", "... general form", "... window touched", "cullAndFilter", "... with the window bounds of the clip before it", "rays", "processColumn with a clean window", "(sum of lives)", "(longest life)", "(columns of the longest)", "clipped column is itself a hit", "-", "-", "passes over windows with a second run", "... whose remaining columns have only one", "passes over windows with a third run", "... whose remaining columns have at most two", "hits of the pass that wrote no pixel"]
 print(f"per frame ({poses} frames {W}x{H} {world}):")
 for i, n in enumerate(names):
+    print(f"  {n:50s} {out[i] / poses:12.1f}     longest wave: {longest[i] / poses:10.1f}")
+for i, n in names_extra.items():
     print(f"  {n:50s} {out[i] / poses:12.1f}     longest wave: {longest[i] / poses:10.1f}")
 sections = ["event loop / other", "window: DDA", "window: records + projections", "clip", "clip: window touched", "cull + filter", "column glue", "side: horizon", "side: pixels",
             "face: horizon", "face: pixels", "skybox pass", "window: waiting for the records", "window: waiting for the face colours"]
